@@ -1,0 +1,146 @@
+/*
+ * nerf_hip.h — C ABI of libnerf_hip.so: the NeRF ray-marching render path on MI355X (gfx950).
+ *
+ * The upstream program (hwan0806/NeRF, a nerf-pytorch fork) has no native interface: its hot path
+ * is Python calling ATen.  Each entry point below replaces the arithmetic of one upstream Python
+ * function (cited per entry as file:line of the upstream tree) and is what a ctypes / cffi binding
+ * on the upstream side would call.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated; the library never allocates,
+ *     frees or retains caller memory;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream); results are ordered like any other work on that stream;
+ *   - return value 0 = success; < 0 = error (NERF_E_*), with a message available from
+ *     nerf_last_error() on the calling thread; argument errors are detected before any launch;
+ *   - tensors are dense row-major with the shapes given; "rays" is the packed per-ray record of
+ *     upstream render(): [o(3) d(3) near far viewdir(3)] with a caller-given row stride in floats;
+ *   - thread-compatible: no global mutable state besides the thread-local error string.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_E_ARG (-1)     /* invalid argument (null pointer, bad size, unsupported shape) */
+#define NERF_E_LAUNCH (-2)  /* HIP reported an error at launch */
+#define NERF_E_ARCH (-3)    /* the current device is not gfx950 */
+
+/* ---- probes ------------------------------------------------------------------------------- */
+int nerf_version(void);                 /* ABI version, currently 1 */
+const char* nerf_arch(void);            /* "gfx950": the only code object in the library */
+const char* nerf_last_error(void);      /* message of the last failing call on this thread */
+int nerf_check_device(void);            /* 0 if the current HIP device can run the kernels */
+
+/* ---- ray generation ----------------------------------------------------------------------- */
+/* get_rays (run_nerf_helpers.py:169-196).  Pixel (row j, col i) -> ray, integer pixel centres.
+ * c2w: device, 12 floats, row-major 3x4.  rays_o, rays_d: [H*W,3].  intr = fx, fy, cx, cy as the
+ * fp32 values of K[0][0], K[1][1], K[0][2], K[1][2]. */
+int nerf_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w,
+                  float* rays_o, float* rays_d, void* stream);
+
+/* ndc_rays (run_nerf_helpers.py:230-255) on n rays; sx = -1/(W/(2 focal)), sy = -1/(H/(2 focal))
+ * evaluated in double by the caller and rounded to fp32, as the upstream scalar arithmetic does.
+ * In-place use (o_out == o_in, d_out == d_in) is allowed. */
+int nerf_ndc_rays(int64_t n, float sx, float sy, float near, const float* o_in, const float* d_in,
+                  float* o_out, float* d_out, void* stream);
+
+/* The ray record built by render() (run_nerf.py:120-149): unit view directions taken from
+ * viewdir_src [n,3] (NULL = no view directions, 8-column record), optional NDC warp of (o,d) with
+ * near plane ndc_near, then [o d near far viewdir].  near_v / far_v: optional per-ray bounds [n]
+ * overriding the scalars. */
+int nerf_pack_rays(int64_t n, const float* rays_o, const float* rays_d, const float* viewdir_src, int ndc,
+                   float sx, float sy, float ndc_near, float near, float far, const float* near_v,
+                   const float* far_v, float* rays, int ray_stride, void* stream);
+
+/* ---- stratified depths + sample positions ------------------------------------------------- */
+/* render_rays (run_nerf.py:419-453).  rays: [n, ray_stride] packed records.  t_vals: [S] device
+ * (the caller's linspace(0,1,S)).  t_rand: [n,S] uniforms or NULL (perturb == 0).  Outputs
+ * z: [n,S], pts: [n,S,3] = o + d*z. */
+int nerf_sample_coarse(int64_t n, int S, const float* rays, int ray_stride, const float* t_vals,
+                       const float* t_rand, int lindisp, float* z, float* pts, void* stream);
+
+/* ---- positional encoding (stand-alone) ---------------------------------------------------- */
+/* Embedder.embed (run_nerf_helpers.py:13-66): x [n,3] -> out [n, 3+6L], per frequency sin then cos. */
+int nerf_encode(int64_t n, int L, const float* x, float* out, void* stream);
+
+/* ---- hierarchical sampling ---------------------------------------------------------------- */
+/* sample_pdf (run_nerf_helpers.py:260-303) + the merge/sort and z_std of render_rays
+ * (run_nerf.py:465-470,485) in one kernel.  z: [n,Sc] coarse depths (ascending);
+ * weights: [n,Sc] compositing weights of the coarse pass (the kernel uses columns 1..Sc-2);
+ * u: [n,Si] uniforms, or [Si] shared by all rays when u_shared != 0 (the deterministic linspace).
+ * Outputs (any may be NULL except z_out): z_out [n,Sc+Si] sorted; pts_out [n,Sc+Si,3];
+ * z_std [n]; samples [n,Si] (unsorted inverse-CDF samples); inds [n,Si] int64 searchsorted(right)
+ * indices.  rays/ray_stride as above (only needed when pts_out != NULL).  Sc >= 3. */
+int nerf_sample_fine(int64_t n, int Sc, int Si, const float* z, const float* weights, const float* u,
+                     int u_shared, const float* rays, int ray_stride, float* z_out, float* pts_out,
+                     float* z_std, float* samples, int64_t* inds, void* stream);
+
+/* sample_pdf alone (run_nerf_helpers.py:260-303): bins [n,n_bins], weights [n,n_bins-1], u as
+ * above -> samples [n,Si] and, if inds != NULL, the int64 searchsorted(right=True) indices. */
+int nerf_sample_pdf(int64_t n, int n_bins, int Si, const float* bins, const float* weights, const float* u,
+                    int u_shared, float* samples, int64_t* inds, void* stream);
+
+/* ---- alpha compositing -------------------------------------------------------------------- */
+/* raw2outputs (run_nerf.py:292-362).  raw: [n,S,4]; z: [n,S]; rays_d: direction of ray i at
+ * rays_d + i*dir_stride (3 floats; dir_stride = 3 for a dense [n,3] array, or the record stride
+ * when pointing at column 3 of the packed rays); noise: [n,S] already scaled by raw_noise_std, or
+ * NULL.  Outputs: rgb [n,3], disp [n], acc [n], weights [n,S], depth [n]. */
+int nerf_composite_fwd(int64_t n, int S, const float* raw, const float* z, const float* rays_d,
+                       int dir_stride, const float* noise, int white_bkgd, float* rgb, float* disp,
+                       float* acc, float* weights, float* depth, void* stream);
+
+/* Backward of the above w.r.t. raw (what autograd derives upstream for run_nerf.py:292-362).
+ * weights: the forward's output.  Upstream gradients: g_rgb [n,3], g_disp [n], g_acc [n],
+ * g_weights [n,S], g_depth [n]; each may be NULL (= zero).  Output d_raw [n,S,4]. */
+int nerf_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays_d,
+                       int dir_stride, const float* noise, int white_bkgd, const float* weights,
+                       const float* g_rgb, const float* g_disp, const float* g_acc,
+                       const float* g_weights, const float* g_depth, float* d_raw, void* stream);
+
+/* ---- the MLP ------------------------------------------------------------------------------ */
+/* The network is NeRF(D=8, W=256, skips=[4]) (run_nerf_helpers.py:73-133) with L=10 / L=4
+ * encodings fused in (run_nerf.py:40-66).  Weights are consumed from a packed stream built by
+ * nerf_pack_weights from the flat concatenation of the module's parameters in state_dict order. */
+int64_t nerf_mlp_n_params(int use_viewdirs, int output_ch);   /* floats in the flat parameter vector */
+int64_t nerf_mlp_packed_floats(int use_viewdirs);             /* floats in a forward stream */
+int64_t nerf_mlp_packed_bwd_floats(int use_viewdirs);         /* floats in a backward (transposed) stream */
+int64_t nerf_mlp_act_floats(int use_viewdirs, int64_t n_pts); /* floats of saved activations for n_pts points */
+int64_t nerf_mlp_scratch_floats(int use_viewdirs, int64_t n_pts); /* floats of backward workspace for n_pts points */
+
+/* Where float `idx` of a packed stream comes from: an index into the flat parameter vector, or -1
+ * for a zero.  backward != 0 selects the transposed stream.  Host-only (layout introspection for
+ * tests and tools); the _table form fills a HOST array of the stream's length. */
+int64_t nerf_pack_source(int use_viewdirs, int output_ch, int backward, int64_t idx);
+int nerf_pack_source_table(int use_viewdirs, int output_ch, int backward, int64_t* table, int64_t n);
+
+/* flat params -> forward stream (and, if packed_bwd != NULL, the transposed stream). */
+int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, float* packed_fwd,
+                      float* packed_bwd, void* stream);
+
+/* NeRF.forward on encoded points (run_nerf_helpers.py:109-133 after run_nerf.py:46-58).
+ * pts [n_pts,3]; viewdirs [n_rays,3] (ray of point p = p / pts_per_ray) or NULL when the network
+ * has no view branch; out [n_pts, out_ch] (out_ch = 4 with view directions, else output_ch).
+ * act: NULL for inference; for training a buffer of nerf_mlp_act_floats() floats receiving the
+ * per-layer activations the backward needs. */
+int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
+                 int use_viewdirs, int output_ch, const float* packed_fwd, float* out, float* act,
+                 void* stream);
+
+/* Backward of nerf_mlp_fwd w.r.t. the parameters (inputs carry no gradient upstream:
+ * run_nerf.py:467 detaches the samples).  d_out [n_pts,out_ch]; act from the forward;
+ * packed_fwd / packed_bwd from nerf_pack_weights; scratch: nerf_mlp_scratch_floats() floats of
+ * workspace; d_params: flat gradient, same layout as the flat parameter vector, OVERWRITTEN. */
+int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float* act,
+                 int use_viewdirs, int output_ch, const float* packed_fwd, const float* packed_bwd,
+                 float* scratch, float* d_params, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

@@ -1,0 +1,62 @@
+"""ctypes binding of libnerf_hip.so (declared in include/nerf_hip.h).
+
+The library is the only implementation of the render-path arithmetic: importing this module
+fails loudly when it has not been built, and nothing here falls back to PyTorch ops.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_int64
+_f = ctypes.c_float
+
+SIGNATURES = {
+    "nerf_version": (_i, []),
+    "nerf_arch": (ctypes.c_char_p, []),
+    "nerf_last_error": (ctypes.c_char_p, []),
+    "nerf_check_device": (_i, []),
+    "nerf_get_rays": (_i, [_i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "nerf_ndc_rays": (_i, [_l, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "nerf_pack_rays": (_i, [_l, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _p]),
+    "nerf_sample_coarse": (_i, [_l, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
+    "nerf_encode": (_i, [_l, _i, _p, _p, _p]),
+    "nerf_sample_fine": (_i, [_l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "nerf_sample_pdf": (_i, [_l, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "nerf_composite_fwd": (_i, [_l, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "nerf_composite_bwd": (_i, [_l, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_mlp_n_params": (_l, [_i, _i]),
+    "nerf_mlp_packed_floats": (_l, [_i]),
+    "nerf_mlp_packed_bwd_floats": (_l, [_i]),
+    "nerf_mlp_act_floats": (_l, [_i, _l]),
+    "nerf_mlp_scratch_floats": (_l, [_i, _l]),
+    "nerf_pack_source": (_l, [_i, _i, _i, _l]),
+    "nerf_pack_source_table": (_i, [_i, _i, _i, _p, _l]),
+    "nerf_pack_weights": (_i, [_i, _i, _p, _p, _p, _p]),
+    "nerf_mlp_fwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "nerf_mlp_bwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the built library is older than the header
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class NerfHipError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise NerfHipError(f"libnerf_hip error {rc}: {lib.nerf_last_error().decode()}")

@@ -1,0 +1,261 @@
+// Alpha compositing along rays (forward and backward w.r.t. the network output).
+//
+// One wavefront per ray, one lane per sample, 64 samples per tile: lane i of a tile loads
+// raw[ray][s0+i] as one 16-byte vector, so a wave reads 1 KiB of contiguous HBM per tile.  The
+// exclusive transmittance product is a 64-lane Hillis-Steele scan carried in fp64 (the PyTorch CPU
+// cumprod accumulates in fp64 and rounds each element to fp32; an fp64 scan reproduces those
+// roundings up to double rounding), with a scalar carry between tiles.  Ray sums are fp64 wave
+// reductions.  HBM-bound: 24*S + 36 bytes per ray forward, 36*S + 24 backward (+4*S with noise).
+#include "common.hpp"
+#pragma clang fp contract(off)
+
+using namespace nerfhip;
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int MAX_TILES = 64;  // backward keeps one carry per 64-sample tile: S <= 4096
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// inclusive product scan over the 64 lanes
+__device__ __forceinline__ double wave_scan_mul(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v *= o;
+    }
+    return v;
+}
+
+// inclusive sum scan, running from the LAST lane towards lane 0
+__device__ __forceinline__ double wave_rscan_add(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_down(v, off, 64);
+        if (lane + off < 64) v += o;
+    }
+    return v;
+}
+
+struct Sample {
+    float4 raw;
+    float z, dist, sig, alpha, keep;  // keep = 1 - alpha + 1e-10 as fp32
+};
+
+__device__ __forceinline__ Sample load_sample(const float* __restrict__ raw, const float* __restrict__ z,
+                                              const float* __restrict__ noise, int64_t base, int s, int S, float dnorm) {
+    Sample q;
+    q.raw = reinterpret_cast<const float4*>(raw)[base + s];
+    q.z = z[base + s];
+    const float gap = (s < S - 1) ? (z[base + s + 1] - q.z) : 1e10f;
+    q.dist = gap * dnorm;
+    q.sig = noise ? (q.raw.w + noise[base + s]) : q.raw.w;
+    const float act = q.sig > 0.0f ? q.sig : (q.sig != q.sig ? q.sig : 0.0f);  // relu, NaN kept
+    q.alpha = 1.0f - expf(-act * q.dist);
+    q.keep = (1.0f - q.alpha) + 1e-10f;
+    return q;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float ray_norm(const float* rr) {
+    const float dx = rr[0], dy = rr[1], dz = rr[2];
+    return sqrtf((dx * dx + dy * dy) + dz * dz);
+}
+
+__global__ void __launch_bounds__(WAVE * WAVES_PER_BLOCK)
+k_composite_fwd(int64_t n, int S, const float* __restrict__ raw, const float* __restrict__ z,
+                const float* __restrict__ rays, int ld, const float* __restrict__ noise, int white,
+                float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc,
+                float* __restrict__ weights, float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (int64_t ray = wave0; ray < n; ray += nwaves) {
+        const float dnorm = ray_norm(rays + ray * ld);
+        const int64_t base = ray * S;
+        double carry = 1.0;  // product of keep over all earlier tiles
+        double sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const bool live = s < S;
+            Sample q;
+            double keep = 1.0;
+            if (live) {
+                q = load_sample(raw, z, noise, base, s, S, dnorm);
+                keep = (double)q.keep;
+            }
+            const double incl = wave_scan_mul(keep, lane);
+            double excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0;
+            const float T = (float)(carry * excl);
+            carry *= __shfl(incl, 63, 64);
+            // the reference rounds the running product to fp32 per element but keeps the fp64 value running
+            if (live) {
+                const float w = q.alpha * T;
+                weights[base + s] = w;
+                sr += (double)(w * sigmoidf(q.raw.x));
+                sg += (double)(w * sigmoidf(q.raw.y));
+                sb += (double)(w * sigmoidf(q.raw.z));
+                sd += (double)(w * q.z);
+                sa += (double)w;
+            }
+        }
+        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+        if (lane == 0) {
+            const float a = (float)sa, d = (float)sd;
+            float r = (float)sr, g = (float)sg, b = (float)sb;
+            if (white) {
+                const float bg = 1.0f - a;
+                r = r + bg; g = g + bg; b = b + bg;
+            }
+            rgb[ray * 3 + 0] = r; rgb[ray * 3 + 1] = g; rgb[ray * 3 + 2] = b;
+            acc[ray] = a;
+            depth[ray] = d;
+            const float q = d / a;
+            disp[ray] = 1.0f / ((q != q) ? q : (q > 1e-10f ? q : 1e-10f));
+        }
+    }
+}
+
+// Backward.  With w_i = alpha_i T_i, T_i = prod_{j<i} keep_j and G_i = dL/dw_i:
+//   dL/dalpha_i = G_i T_i - (sum_{j>i} G_j w_j) / keep_i,   dalpha_i/dsigma_i = dist_i (1 - alpha_i) [sigma_i > 0],
+//   dL/draw_c  = w_i g_rgb[c] s_c (1 - s_c).
+__global__ void __launch_bounds__(WAVE * WAVES_PER_BLOCK)
+k_composite_bwd(int64_t n, int S, const float* __restrict__ raw, const float* __restrict__ z,
+                const float* __restrict__ rays, int ld, const float* __restrict__ noise, int white,
+                const float* __restrict__ weights, const float* __restrict__ g_rgb, const float* __restrict__ g_disp,
+                const float* __restrict__ g_acc, const float* __restrict__ g_weights,
+                const float* __restrict__ g_depth, float* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int ntiles = (S + 63) / 64;
+    __shared__ double s_carry[WAVES_PER_BLOCK][MAX_TILES];
+    for (int64_t ray = wave0; ray < n; ray += nwaves) {
+        const float dnorm = ray_norm(rays + ray * ld);
+        const int64_t base = ray * S;
+        float gr = 0, gg = 0, gb = 0, ga = 0, gd = 0;
+        if (g_rgb) { gr = g_rgb[ray * 3 + 0]; gg = g_rgb[ray * 3 + 1]; gb = g_rgb[ray * 3 + 2]; }
+        if (g_acc) ga = g_acc[ray];
+        if (g_depth) gd = g_depth[ray];
+        if (white) ga = ga - ((gr + gg) + gb);
+        if (g_disp) {
+            // disp = 1 / max(1e-10, depth/acc): needs the forward sums again
+            double sd = 0, sa = 0;
+            for (int s = lane; s < S; s += 64) {
+                const float w = weights[base + s];
+                sd += (double)(w * z[base + s]);
+                sa += (double)w;
+            }
+            const float d = (float)wave_sum(sd), a = (float)wave_sum(sa);
+            const float q = d / a;
+            if (q > 1e-10f) {
+                const float gq = -g_disp[ray] / (q * q);
+                gd = gd + gq / a;
+                ga = ga - gq * q / a;
+            }
+        }
+        // carry-in transmittance of every tile, rebuilt exactly as the forward did
+        double* carry_in = s_carry[threadIdx.x >> 6];
+        {
+            double carry = 1.0;
+            for (int t = 0; t < ntiles; ++t) {
+                if (lane == 0) carry_in[t] = carry;
+                if (t == ntiles - 1) break;
+                const int s = t * 64 + lane;
+                double keep = 1.0;
+                if (s < S) keep = (double)load_sample(raw, z, noise, base, s, S, dnorm).keep;
+                carry *= __shfl(wave_scan_mul(keep, lane), 63, 64);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        double suffix = 0.0;  // sum of G_j w_j over all later tiles
+        for (int t = ntiles - 1; t >= 0; --t) {
+            const int s = t * 64 + lane;
+            const bool live = s < S;
+            Sample q;
+            float w = 0.0f, G = 0.0f, sr = 0, sg = 0, sb = 0;
+            double keep = 1.0;
+            if (live) {
+                q = load_sample(raw, z, noise, base, s, S, dnorm);
+                keep = (double)q.keep;
+                w = weights[base + s];
+                sr = sigmoidf(q.raw.x); sg = sigmoidf(q.raw.y); sb = sigmoidf(q.raw.z);
+                G = (((gr * sr + gg * sg) + gb * sb) + gd * q.z) + ga;
+                if (g_weights) G = G + g_weights[base + s];
+            }
+            const double incl_p = wave_scan_mul(keep, lane);
+            double excl_p = __shfl_up(incl_p, 1, 64);
+            if (lane == 0) excl_p = 1.0;
+            const float T = (float)(carry_in[t] * excl_p);
+            const double gw = (double)G * (double)w;
+            const double incl = wave_rscan_add(gw, lane);
+            double after = __shfl_down(incl, 1, 64);
+            if (lane == 63) after = 0.0;
+            after += suffix;
+            suffix += __shfl(incl, 0, 64);
+            if (live) {
+                float4 o;
+                o.x = w * gr * (sr * (1.0f - sr));
+                o.y = w * gg * (sg * (1.0f - sg));
+                o.z = w * gb * (sb * (1.0f - sb));
+                float dsig = 0.0f;
+                if (q.sig > 0.0f) {
+                    const float dalpha = (float)((double)G * (double)T - after / (double)q.keep);
+                    dsig = dalpha * (q.dist * (1.0f - q.alpha));
+                }
+                o.w = dsig;
+                reinterpret_cast<float4*>(d_raw)[base + s] = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+inline int grid_rays(int64_t n) {
+    int64_t g = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const int64_t cap = 256 * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int nerf_composite_fwd(int64_t n, int S, const float* raw, const float* z, const float* rays, int ray_stride,
+                       const float* noise, int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
+                       float* depth, void* stream) {
+    NERF_REQUIRE(n >= 0 && S >= 1, "nerf_composite_fwd: n=%lld S=%d", (long long)n, S);
+    NERF_REQUIRE(ray_stride >= 3, "nerf_composite_fwd: dir_stride=%d < 3", ray_stride);
+    if (n == 0) return 0;
+    NERF_REQUIRE(raw && z && rays && rgb && disp && acc && weights && depth, "nerf_composite_fwd: null pointer");
+    NERF_REQUIRE((reinterpret_cast<uintptr_t>(raw) & 15) == 0, "nerf_composite_fwd: raw must be 16-byte aligned");
+    hipLaunchKernelGGL(k_composite_fwd, dim3(grid_rays(n)), dim3(WAVE * WAVES_PER_BLOCK), 0, as_stream(stream), n, S,
+                       raw, z, rays, ray_stride, noise, white_bkgd, rgb, disp, acc, weights, depth);
+    return launched("nerf_composite_fwd");
+}
+
+int nerf_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, int ray_stride,
+                       const float* noise, int white_bkgd, const float* weights, const float* g_rgb,
+                       const float* g_disp, const float* g_acc, const float* g_weights, const float* g_depth,
+                       float* d_raw, void* stream) {
+    NERF_REQUIRE(n >= 0 && S >= 1 && S <= 64 * MAX_TILES, "nerf_composite_bwd: n=%lld S=%d (S <= %d)", (long long)n, S,
+                 64 * MAX_TILES);
+    NERF_REQUIRE(ray_stride >= 3, "nerf_composite_bwd: dir_stride=%d < 3", ray_stride);
+    if (n == 0) return 0;
+    NERF_REQUIRE(raw && z && rays && weights && d_raw, "nerf_composite_bwd: null pointer");
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(d_raw)) & 15) == 0,
+                 "nerf_composite_bwd: raw and d_raw must be 16-byte aligned");
+    hipLaunchKernelGGL(k_composite_bwd, dim3(grid_rays(n)), dim3(WAVE * WAVES_PER_BLOCK), 0, as_stream(stream), n, S,
+                       raw, z, rays, ray_stride, noise, white_bkgd, weights, g_rgb, g_disp, g_acc, g_weights, g_depth,
+                       d_raw);
+    return launched("nerf_composite_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// Fused positional encoding + NeRF MLP forward on MFMA (fp32 in, fp32 accumulate).
+//
+// One workgroup = 4 wavefronts = 128 points; each wavefront carries 32 points through all layers.
+// The activations of a wavefront never leave its registers: the 32x32 accumulator tiles of
+// v_mfma_f32_32x32x2_f32 (column = point on the lane, row = feature in the register) are used
+// directly as the B operands of the next layer (see mlp_layout.hpp).  Only the weights move: the
+// packed stream is pulled through a two-slab LDS ring (16 KiB per slab) with global_load_lds, each
+// wave fetching a quarter of the next slab while all four consume the current one, so per
+// workgroup the whole 2.3 MiB stream is read once from L2 and every A operand is one
+// ds_read_b128 per four MFMAs.  ReLU/bias run on the VALU between layers; the 1- and 3-row heads
+// (alpha, rgb) are VALU dot products on the register-resident activations.
+//
+// Bound: MFMA.  9280 MFMAs (4096 FLOP each) per 32 points = 1.188 MFLOP per point, of which
+// 1.187 MFLOP is algorithmic (the rest is zero padding of the 63/27-wide inputs).
+#include "common.hpp"
+#include "mlp_layout.hpp"
+#include <utility>
+
+using namespace nerfhip;
+using namespace nerflayout;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int RING_FLOATS = 2 * SLAB_FLOATS;
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// The weight stream as seen by one wave: a double-buffered slab ring in LDS.
+struct Stream {
+    const float* g;   // this lane's source pointer for block 4*wave of slab 0
+    float* ring;      // LDS ring base
+    float* mine;      // this wave's destination inside a slab (wave-uniform)
+    int next;         // next slab to consume
+    int nslabs;
+
+    __device__ __forceinline__ void fetch(int slab) {
+        const float* src = g + (int64_t)slab * SLAB_FLOATS;
+        float* dst = mine + (slab & 1) * SLAB_FLOATS;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
+    }
+    // Make slab `next` readable, start fetching the one after it, return this lane's read pointer.
+    __device__ __forceinline__ const float* advance(int lane) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's quarter of slab `next` has landed; all reads of the other buffer are done
+        const float* cur = ring + (next & 1) * SLAB_FLOATS + lane * 4;
+        if (next + 1 < nslabs) fetch(next + 1);
+        ++next;
+        return cur;
+    }
+};
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// compile-time loop: body.template operator()<i>() for i = 0..N-1.  Register tiles are indexed by
+// these constants only; a run-time index would send the whole tile array to scratch memory.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f.template operator()<I>(), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// acc[to] (+)= sum over NIN input tiles: one section of NOUT*NIN*4 blocks = NOUT*NIN/4 slabs.
+// The LDS reads run DEPTH blocks ahead of the MFMAs that consume them, also across the slab barrier:
+// the last MFMAs of a slab issue after the barrier and behind the first reads of the next slab, so
+// neither the LDS latency nor the barrier leaves the matrix pipe idle.
+template <int NOUT, int NIN, bool ACCUM, typename InTile>
+__device__ __forceinline__ void run_section(Stream& st, int lane, f32x16 (&acc)[8], InTile in_tile) {
+    constexpr int NB = NOUT * NIN * 4, DEPTH = 2;
+    static_assert(NB % SLAB_BLOCKS == 0, "sections are whole slabs");
+    f32x4 abuf[DEPTH + 1];
+    const float* cur = nullptr;
+    static_for<NB + DEPTH>([&]<int I>() {
+        if constexpr (I < NB) {
+            if constexpr (I % SLAB_BLOCKS == 0) cur = st.advance(lane);
+            abuf[I % (DEPTH + 1)] = *reinterpret_cast<const f32x4*>(cur + (I % SLAB_BLOCKS) * BLOCK_FLOATS);
+        }
+        if constexpr (I >= DEPTH) {
+            constexpr int b = I - DEPTH;
+            constexpr int to = b / (NIN * 4), ti = (b >> 2) % NIN, q = b & 3;
+            const f32x4 a = abuf[b % (DEPTH + 1)];
+            if constexpr (!ACCUM && ti == 0 && q == 0) {
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc[to] = mfma(a[0], in_tile.template operator()<ti>()[0], zero);
+            } else {
+                acc[to] = mfma(a[0], in_tile.template operator()<ti>()[4 * q + 0], acc[to]);
+            }
+            acc[to] = mfma(a[1], in_tile.template operator()<ti>()[4 * q + 1], acc[to]);
+            acc[to] = mfma(a[2], in_tile.template operator()<ti>()[4 * q + 2], acc[to]);
+            acc[to] = mfma(a[3], in_tile.template operator()<ti>()[4 * q + 3], acc[to]);
+        }
+        // keep the read of block I ahead of the MFMAs of block I-DEPTH+1: the scheduler would otherwise sink
+        // every read to just before its first use and expose the LDS latency once per block pair
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// A[t] = act(B[t] + bias)
+template <int NT, bool RELU>
+__device__ __forceinline__ void epilogue(f32x16 (&A)[8], const f32x16 (&B)[8], const float* bias_lds, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* bp = bias_lds + t * 32 + h * 16;
+        f32x16 v = B[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = v[4 * i + e] + bb[e];
+                if (RELU) y = fmaxf(y, 0.0f);
+                v[4 * i + e] = y;
+            }
+        }
+        A[t] = v;
+    }
+}
+
+// Save NT activation tiles as feature-major rows.  `rows` is wave-uniform (scalar base), `lane_off` the
+// per-lane element offset 4*half*ldp + point, so each store is scalar base + 32-bit vector offset.
+template <int NT>
+__device__ __forceinline__ void save_tiles(const f32x16 (&A)[8], float* rows, int64_t ldp, uint32_t lane_off, float msk) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* row = rows + (int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * ldp;
+            row[lane_off] = A[t][r] * msk;
+        }
+}
+
+// dot product of the register-resident activations (NT tiles) with a head row stored as [tile][half][16]
+template <int NT>
+__device__ __forceinline__ float head_dot(const f32x16 (&A)[8], const float* w_lds, int h) {
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* wp = w_lds + t * 32 + h * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wp + 4 * i);
+            s0 = fmaf(A[t][4 * i + 0], w[0], s0);
+            s1 = fmaf(A[t][4 * i + 1], w[1], s1);
+            s0 = fmaf(A[t][4 * i + 2], w[2], s0);
+            s1 = fmaf(A[t][4 * i + 3], w[3], s1);
+        }
+    }
+    const float s = s0 + s1;
+    return s + __shfl_xor(s, 32, 64);  // the two lane halves hold disjoint feature sets of one point
+}
+
+__device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
+
+template <bool VIEWDIRS, bool SAVE>
+__global__ void __launch_bounds__(THREADS, 1)
+k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
+          int output_ch, const float* __restrict__ packed, float* __restrict__ out, float* __restrict__ act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ring = smem;
+    float* aux = smem + RING_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int64_t p = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + (lane & 31);
+    const bool valid = p < n_pts;
+    const int64_t pl = valid ? p : n_pts - 1;
+    const int64_t ldp = padded_points(n_pts);
+    constexpr bool save = SAVE;
+
+    // aux tables -> LDS (plain loads, before the ring starts)
+    const int stream_blocks = fwd_stream_blocks(VIEWDIRS ? 1 : 0);
+    {
+        const float* gaux = packed + (int64_t)stream_blocks * BLOCK_FLOATS;
+        for (int i = tid * 4; i < AUX_FLOATS; i += THREADS * 4)
+            *reinterpret_cast<f32x4*>(aux + i) = *reinterpret_cast<const f32x4*>(gaux + i);
+    }
+
+    // ---- positional encoding into register tiles (slot maps: mlp_layout.hpp)
+    f32x16 E[2], D;
+    {
+        const float x0 = pts[pl * 3 + 0], x1 = pts[pl * 3 + 1], x2 = pts[pl * 3 + 2];
+        E[0][0] = h ? x2 : x0;
+        E[0][1] = h ? 0.0f : x1;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            const int c = 15 * h + i, k = c / 3, d = c - 3 * k;
+            const float arg = (d == 0 ? x0 : (d == 1 ? x1 : x2)) * pow2i(k);
+            float sn, cs;
+            sincosf(arg, &sn, &cs);
+            const int s = 2 + 2 * i;
+            if (s < 16) { E[0][s] = sn; E[0][s + 1] = cs; } else { E[1][s - 16] = sn; E[1][s - 15] = cs; }
+        }
+        if (VIEWDIRS) {
+            const int64_t ray = pl / pts_per_ray;
+            const float v0 = viewdirs[ray * 3 + 0], v1 = viewdirs[ray * 3 + 1], v2 = viewdirs[ray * 3 + 2];
+            D[0] = h ? v2 : v0;
+            D[1] = h ? 0.0f : v1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int c = 6 * h + i, k = c / 3, d = c - 3 * k;
+                const float arg = (d == 0 ? v0 : (d == 1 ? v1 : v2)) * pow2i(k);
+                float sn, cs;
+                sincosf(arg, &sn, &cs);
+                D[2 + 2 * i] = sn;
+                D[3 + 2 * i] = cs;
+            }
+            D[14] = 0.0f;
+            D[15] = 0.0f;
+        }
+        if constexpr (save) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                // row of slot s: the two halves' features differ by a constant per slot except for the padding slot
+                const int f0 = enc_pts_feature(s, 0), f1 = enc_pts_feature(s, 1);
+                const int f = h ? (f1 < 0 ? 63 : f1) : f0;
+                const float v = (valid && !(h && f1 < 0)) ? (s < 16 ? E[0][s] : E[1][s - 16]) : 0.0f;
+                act[(int64_t)(ACT_ENC_PTS + f) * ldp + p] = v;
+            }
+            if (VIEWDIRS) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    // slots 14,15 and slot 1 of the upper half carry no feature: they zero the padding rows 27..31
+                    const int f0 = s < 14 ? enc_dirs_feature(s, 0) : 27 + (s - 14), f1 = enc_dirs_feature(s, 1);
+                    const int g1 = s == 1 ? 29 : (s == 14 ? 30 : (s == 15 ? 31 : f1));
+                    const int f = h ? g1 : f0;
+                    const bool real = h ? (f1 >= 0) : (s < 14);
+                    act[(int64_t)(ACT_ENC_DIRS + f) * ldp + p] = (valid && real) ? D[s] : 0.0f;
+                }
+            }
+        }
+    }
+
+    Stream st;
+    st.ring = ring;
+    st.mine = ring + wave * 4 * BLOCK_FLOATS;
+    st.g = packed + wave * 4 * BLOCK_FLOATS + lane * 4;
+    st.next = 0;
+    st.nslabs = stream_blocks / SLAB_BLOCKS;
+    __syncthreads();  // aux visible; no glds in flight yet
+    st.fetch(0);
+
+    f32x16 A[8], B[8];
+    const float msk = valid ? 1.0f : 0.0f;  // padding columns of the saved activations must be zero
+    const uint32_t lane_off = (uint32_t)(4 * h * ldp + p);
+
+    // layer 0: encoded position -> B
+    run_section<8, 2, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return E[ti]; });
+    epilogue<8, true>(A, B, aux + AUX_BIAS, h);
+    if constexpr (save) save_tiles<8>(A, act + (int64_t)ACT_H0 * ldp, ldp, lane_off, msk);
+
+    float sigma = 0.0f;
+    const int n_hidden = VIEWDIRS ? 9 : 8;  // layers 1..7, then feature_linear as "layer 8"
+#pragma unroll 1
+    for (int l = 1; l < n_hidden; ++l) {
+        run_section<8, 8, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return A[ti]; });
+        if (l == 5) run_section<8, 2, true>(st, lane, B, [&]<int ti>() -> const f32x16& { return E[ti]; });
+        const float* bias = aux + AUX_BIAS + l * 256;
+        if (l < 8) epilogue<8, true>(A, B, bias, h);
+        else epilogue<8, false>(A, B, bias, h);
+        if constexpr (save) save_tiles<8>(A, act + (int64_t)(ACT_H0 + 256 * l) * ldp, ldp, lane_off, msk);  // l == 8: ACT_FEAT
+        if (VIEWDIRS && l == 7) sigma = head_dot<8>(A, aux + AUX_HEAD, h) + aux[AUX_HEAD + 256 + 384];
+    }
+
+    if (VIEWDIRS) {
+        run_section<4, 9, false>(st, lane, B, [&]<int ti>() -> const f32x16& { if constexpr (ti < 8) return A[ti]; else return D; });
+        epilogue<4, true>(A, B, aux + AUX_BIAS + 9 * 256, h);
+        if constexpr (save) save_tiles<4>(A, act + (int64_t)ACT_VIEWS * ldp, ldp, lane_off, msk);
+        const float* wrgb = aux + AUX_HEAD + 256;
+        const float* hb = aux + AUX_HEAD + 256 + 384;
+        const float r = head_dot<4>(A, wrgb, h) + hb[1];
+        const float g = head_dot<4>(A, wrgb + 128, h) + hb[2];
+        const float b = head_dot<4>(A, wrgb + 256, h) + hb[3];
+        if (valid && h == 0) {
+            f32x4 o = {r, g, b, sigma};
+            *reinterpret_cast<f32x4*>(out + p * 4) = o;
+        }
+    } else {
+        for (int c = 0; c < output_ch; ++c) {
+            const float v = head_dot<8>(A, aux + AUX_HEAD + c * 256, h) + aux[AUX_HEAD + output_ch * 256 + c];
+            if (valid && h == 0) out[p * output_ch + c] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack(int use_viewdirs, int output_ch, const float* __restrict__ params,
+                                              float* __restrict__ fwd, int64_t n_fwd, float* __restrict__ bwd,
+                                              int64_t n_bwd) {
+    const int64_t total = n_fwd + n_bwd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_fwd) {
+            const int64_t s = fwd_source(use_viewdirs, output_ch, i);
+            fwd[i] = s < 0 ? 0.0f : params[s];
+        } else {
+            const int64_t s = bwd_source(use_viewdirs, output_ch, i - n_fwd);
+            bwd[i - n_fwd] = s < 0 ? 0.0f : params[s];
+        }
+    }
+}
+
+constexpr size_t FWD_LDS_BYTES = (RING_FLOATS + AUX_FLOATS) * sizeof(float);
+
+}  // namespace
+
+extern "C" {
+
+int64_t nerf_mlp_n_params(int use_viewdirs, int output_ch) { return param_offsets(use_viewdirs, output_ch).total; }
+int64_t nerf_mlp_packed_floats(int use_viewdirs) { return fwd_packed_floats(use_viewdirs); }
+int64_t nerf_mlp_packed_bwd_floats(int use_viewdirs) { return bwd_packed_floats(use_viewdirs); }
+int64_t nerf_mlp_act_floats(int use_viewdirs, int64_t n_pts) { return act_floats(use_viewdirs, n_pts); }
+
+int64_t nerf_pack_source(int use_viewdirs, int output_ch, int backward, int64_t idx) {
+    return backward ? bwd_source(use_viewdirs, output_ch, idx) : fwd_source(use_viewdirs, output_ch, idx);
+}
+
+int nerf_pack_source_table(int use_viewdirs, int output_ch, int backward, int64_t* table /* HOST */, int64_t n) {
+    NERF_REQUIRE(table, "nerf_pack_source_table: null pointer");
+    const int64_t want = backward ? bwd_packed_floats(use_viewdirs) : fwd_packed_floats(use_viewdirs);
+    NERF_REQUIRE(n == want, "nerf_pack_source_table: table has %lld entries, stream has %lld", (long long)n, (long long)want);
+    for (int64_t i = 0; i < n; ++i)
+        table[i] = backward ? bwd_source(use_viewdirs, output_ch, i) : fwd_source(use_viewdirs, output_ch, i);
+    return 0;
+}
+
+int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, float* packed_fwd, float* packed_bwd,
+                      void* stream) {
+    NERF_REQUIRE(params && packed_fwd, "nerf_pack_weights: null pointer");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_pack_weights: output_ch=%d not in 1..8",
+                 output_ch);
+    const int64_t nf = fwd_packed_floats(use_viewdirs), nb = packed_bwd ? bwd_packed_floats(use_viewdirs) : 0;
+    hipLaunchKernelGGL(k_pack, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, params, packed_fwd,
+                       nf, packed_bwd, nb);
+    return launched("nerf_pack_weights");
+}
+
+int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
+                 int output_ch, const float* packed_fwd, float* out, float* act, void* stream) {
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd: n_pts=%lld", (long long)n_pts);
+    if (n_pts == 0) return 0;
+    NERF_REQUIRE(pts && packed_fwd && out, "nerf_mlp_fwd: null pointer");
+    NERF_REQUIRE(!use_viewdirs || (viewdirs && pts_per_ray >= 1), "nerf_mlp_fwd: view branch needs viewdirs and pts_per_ray >= 1");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_fwd: output_ch=%d not in 1..8", output_ch);
+    NERF_REQUIRE((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                 "nerf_mlp_fwd: packed_fwd and out must be 16-byte aligned");
+    const int64_t blocks = (n_pts + TILE_PTS - 1) / TILE_PTS;
+    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd: n_pts=%lld too large for one launch", (long long)n_pts);
+    NERF_REQUIRE(!act || padded_points(n_pts) * 4 * 5 < (int64_t)0xffffffff, "nerf_mlp_fwd: n_pts=%lld too large to save activations in one call", (long long)n_pts);
+    auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)FWD_LDS_BYTES);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), FWD_LDS_BYTES, as_stream(stream), n_pts, ppr, pts,
+                           vd, och, packed_fwd, out, act);
+        return launched("nerf_mlp_fwd");
+    };
+    if (use_viewdirs) return act ? go(k_mlp_fwd<true, true>, pts_per_ray, viewdirs, 4) : go(k_mlp_fwd<true, false>, pts_per_ray, viewdirs, 4);
+    return act ? go(k_mlp_fwd<false, true>, 1, nullptr, output_ch) : go(k_mlp_fwd<false, false>, 1, nullptr, output_ch);
+}
+
+}  // extern "C"

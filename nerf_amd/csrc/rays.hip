@@ -1,0 +1,194 @@
+// Ray generation, NDC warp, stratified depth sampling and the stand-alone positional encoding.
+//
+// All four are streaming kernels bounded by HBM: one thread per output element (or per ray where
+// the per-ray inputs dominate), consecutive lanes on consecutive addresses.  Arithmetic follows the
+// upstream elementwise op order with one fp32 rounding per op (no FMA contraction), so results are
+// bit-identical to the PyTorch CPU evaluation wherever libm differences cannot enter.
+#include "common.hpp"
+#pragma clang fp contract(off)
+
+using namespace nerfhip;
+
+namespace {
+
+// run_nerf_helpers.py:169-196.  dirs = [(i-cx)/fx, -(j-cy)/fy, -1]; d = sum_k dirs[k] * c2w[r][k].
+__global__ void __launch_bounds__(256) k_get_rays(int H, int W, float fx, float fy, float cx, float cy,
+                                                  const float* __restrict__ c2w, float* __restrict__ rays_o,
+                                                  float* __restrict__ rays_d) {
+    const int64_t total = (int64_t)H * W * 3;
+    // one thread per output float: stores of a wave are 256 contiguous bytes in each array
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = e / 3;
+        const int r = (int)(e - pix * 3);
+        const int j = (int)(pix / W), i = (int)(pix - (int64_t)j * W);
+        const float dx = ((float)i - cx) / fx;
+        const float dy = -(((float)j - cy) / fy);
+        const float dz = -1.0f;
+        const float m0 = c2w[r * 4 + 0], m1 = c2w[r * 4 + 1], m2 = c2w[r * 4 + 2];
+        rays_d[e] = (dx * m0 + dy * m1) + dz * m2;
+        rays_o[e] = c2w[r * 4 + 3];
+    }
+}
+
+// run_nerf_helpers.py:230-255.
+__global__ void __launch_bounds__(256) k_ndc(int64_t n, float sx, float sy, float near, const float* o_in,
+                                             const float* d_in, float* o_out, float* d_out) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        float ox = o_in[p * 3 + 0], oy = o_in[p * 3 + 1], oz = o_in[p * 3 + 2];
+        const float dx = d_in[p * 3 + 0], dy = d_in[p * 3 + 1], dz = d_in[p * 3 + 2];
+        const float t = -(near + oz) / dz;
+        ox = ox + t * dx;
+        oy = oy + t * dy;
+        oz = oz + t * dz;
+        const float o0 = sx * ox / oz;
+        const float o1 = sy * oy / oz;
+        const float o2 = 1.0f + (2.0f * near) / oz;
+        const float d0 = sx * (dx / dz - ox / oz);
+        const float d1 = sy * (dy / dz - oy / oz);
+        const float d2 = (-2.0f * near) / oz;
+        o_out[p * 3 + 0] = o0; o_out[p * 3 + 1] = o1; o_out[p * 3 + 2] = o2;
+        d_out[p * 3 + 0] = d0; d_out[p * 3 + 1] = d1; d_out[p * 3 + 2] = d2;
+    }
+}
+
+// run_nerf.py:419-453.  One thread per (ray, sample).
+__global__ void __launch_bounds__(256) k_sample_coarse(int64_t n, int S, const float* __restrict__ rays, int ld,
+                                                       const float* __restrict__ t_vals,
+                                                       const float* __restrict__ t_rand, int lindisp,
+                                                       float* __restrict__ z_out, float* __restrict__ pts) {
+    const int64_t total = n * S;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ray = e / S;
+        const int s = (int)(e - ray * S);
+        const float* rr = rays + ray * ld;
+        const float near = rr[6], far = rr[7];
+        auto depth = [&](int k) -> float {
+            const float t = t_vals[k];
+            if (!lindisp) return near * (1.0f - t) + far * t;
+            return 1.0f / ((1.0f / near) * (1.0f - t) + (1.0f / far) * t);
+        };
+        float z = depth(s);
+        if (t_rand) {
+            const float lo = (s == 0) ? z : 0.5f * (z + depth(s - 1));
+            const float hi = (s == S - 1) ? z : 0.5f * (depth(s + 1) + z);
+            z = lo + (hi - lo) * t_rand[e];
+        }
+        z_out[e] = z;
+        if (pts) {
+            pts[e * 3 + 0] = rr[0] + rr[3] * z;
+            pts[e * 3 + 1] = rr[1] + rr[4] * z;
+            pts[e * 3 + 2] = rr[2] + rr[5] * z;
+        }
+    }
+}
+
+// run_nerf_helpers.py:13-66.  One thread per output element; frequencies are exact powers of two.
+__global__ void __launch_bounds__(256) k_encode(int64_t n, int L, const float* __restrict__ x, float* __restrict__ out) {
+    const int width = 3 + 6 * L;
+    const int64_t total = n * width;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / width;
+        const int c = (int)(e - p * width);
+        float v;
+        if (c < 3) {
+            v = x[p * 3 + c];
+        } else {
+            const int k = (c - 3) / 6, w = (c - 3) - k * 6;
+            const float arg = x[p * 3 + (w % 3)] * (float)(1 << k);
+            v = (w < 3) ? sinf(arg) : cosf(arg);
+        }
+        out[e] = v;
+    }
+}
+
+// run_nerf.py:120-149: unit view directions (from the un-warped directions), optional NDC warp, and
+// the packed record [o d near far (viewdir)].  One thread per ray.
+__global__ void __launch_bounds__(256) k_pack_rays(int64_t n, const float* __restrict__ o_in, const float* __restrict__ d_in,
+                                                   const float* __restrict__ vd_src, int ndc, float sx, float sy,
+                                                   float ndc_near, float near, float far,
+                                                   const float* __restrict__ near_v, const float* __restrict__ far_v,
+                                                   float* __restrict__ out, int ld) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        float ox = o_in[p * 3 + 0], oy = o_in[p * 3 + 1], oz = o_in[p * 3 + 2];
+        float dx = d_in[p * 3 + 0], dy = d_in[p * 3 + 1], dz = d_in[p * 3 + 2];
+        float* r = out + p * ld;
+        if (vd_src) {
+            const float vx = vd_src[p * 3 + 0], vy = vd_src[p * 3 + 1], vz = vd_src[p * 3 + 2];
+            const float nrm = sqrtf((vx * vx + vy * vy) + vz * vz);
+            r[8] = vx / nrm; r[9] = vy / nrm; r[10] = vz / nrm;
+        }
+        if (ndc) {
+            const float t = -(ndc_near + oz) / dz;
+            ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz;
+            const float o0 = sx * ox / oz, o1 = sy * oy / oz, o2 = 1.0f + (2.0f * ndc_near) / oz;
+            const float d0 = sx * (dx / dz - ox / oz), d1 = sy * (dy / dz - oy / oz), d2 = (-2.0f * ndc_near) / oz;
+            ox = o0; oy = o1; oz = o2; dx = d0; dy = d1; dz = d2;
+        }
+        r[0] = ox; r[1] = oy; r[2] = oz; r[3] = dx; r[4] = dy; r[5] = dz;
+        r[6] = near_v ? near_v[p] : near;
+        r[7] = far_v ? far_v[p] : far;
+    }
+}
+
+inline int grid_for(int64_t total, int block = 256) {
+    int64_t g = (total + block - 1) / block;
+    const int64_t cap = 256 * 8;  // 8 blocks per CU, grid-stride beyond that
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int nerf_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w, float* rays_o,
+                  float* rays_d, void* stream) {
+    NERF_REQUIRE(H > 0 && W > 0, "nerf_get_rays: H=%d W=%d", H, W);
+    NERF_REQUIRE(c2w && rays_o && rays_d, "nerf_get_rays: null pointer");
+    NERF_REQUIRE(fx != 0.0f && fy != 0.0f, "nerf_get_rays: zero focal length");
+    hipLaunchKernelGGL(k_get_rays, dim3(grid_for((int64_t)H * W * 3)), dim3(256), 0, as_stream(stream), H, W, fx, fy,
+                       cx, cy, c2w, rays_o, rays_d);
+    return launched("nerf_get_rays");
+}
+
+int nerf_ndc_rays(int64_t n, float sx, float sy, float near, const float* o_in, const float* d_in, float* o_out,
+                  float* d_out, void* stream) {
+    NERF_REQUIRE(n >= 0, "nerf_ndc_rays: n=%lld", (long long)n);
+    if (n == 0) return 0;
+    NERF_REQUIRE(o_in && d_in && o_out && d_out, "nerf_ndc_rays: null pointer");
+    hipLaunchKernelGGL(k_ndc, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), n, sx, sy, near, o_in, d_in, o_out,
+                       d_out);
+    return launched("nerf_ndc_rays");
+}
+
+int nerf_pack_rays(int64_t n, const float* rays_o, const float* rays_d, const float* viewdir_src, int ndc, float sx,
+                   float sy, float ndc_near, float near, float far, const float* near_v, const float* far_v,
+                   float* rays, int ray_stride, void* stream) {
+    NERF_REQUIRE(n >= 0, "nerf_pack_rays: n=%lld", (long long)n);
+    NERF_REQUIRE(ray_stride >= (viewdir_src ? 11 : 8), "nerf_pack_rays: ray_stride=%d too small", ray_stride);
+    if (n == 0) return 0;
+    NERF_REQUIRE(rays_o && rays_d && rays, "nerf_pack_rays: null pointer");
+    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), n, rays_o, rays_d, viewdir_src, ndc,
+                       sx, sy, ndc_near, near, far, near_v, far_v, rays, ray_stride);
+    return launched("nerf_pack_rays");
+}
+
+int nerf_sample_coarse(int64_t n, int S, const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
+                       int lindisp, float* z, float* pts, void* stream) {
+    NERF_REQUIRE(n >= 0 && S >= 1, "nerf_sample_coarse: n=%lld S=%d", (long long)n, S);
+    NERF_REQUIRE(ray_stride >= 8, "nerf_sample_coarse: ray_stride=%d < 8", ray_stride);
+    if (n == 0) return 0;
+    NERF_REQUIRE(rays && t_vals && z, "nerf_sample_coarse: null pointer");
+    hipLaunchKernelGGL(k_sample_coarse, dim3(grid_for(n * S)), dim3(256), 0, as_stream(stream), n, S, rays, ray_stride,
+                       t_vals, t_rand, lindisp, z, pts);
+    return launched("nerf_sample_coarse");
+}
+
+int nerf_encode(int64_t n, int L, const float* x, float* out, void* stream) {
+    NERF_REQUIRE(n >= 0 && L >= 0 && L <= 24, "nerf_encode: n=%lld L=%d", (long long)n, L);
+    if (n == 0) return 0;
+    NERF_REQUIRE(x && out, "nerf_encode: null pointer");
+    hipLaunchKernelGGL(k_encode, dim3(grid_for(n * (3 + 6 * L))), dim3(256), 0, as_stream(stream), n, L, x, out);
+    return launched("nerf_encode");
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// Hierarchical (inverse-CDF) depth sampling fused with the merge of coarse and fine depths.
+//
+// One wavefront per ray; the ray's coarse depths, bin mid-points, cdf and the merged depth list
+// live in LDS (about 8*(Sc+Si) bytes per wave).  Stages, all inside the wave:
+//   1. weights+1e-5 and their sum, in the exact association order of ATen's vectorised fp32 sum
+//      (8 interleaved partial sums with a 4-way cascade), so pdf = w/sum has the reference's bits;
+//   2. cdf = inclusive prefix sum carried in fp64 (64-lane scan + carry per tile).  Every partial
+//      sum of fp32 pdf values >= 2^-27 that totals <= 1 is exactly representable in fp64, so the
+//      scan order cannot change a bit relative to the sequential fp64 accumulation of ATen's cumsum;
+//   3. per uniform: binary search (searchsorted, right=True), clamp, gather, lerp, in fp32 with
+//      one rounding per op;
+//   4. z_std in fp64; 5. rank sort of the Sc+Si depths (stable, NaN last), coalesced write-out
+//      of z and of the sample positions o + d*z.
+// HBM traffic per ray: read 8*Sc (+4*Si uniforms), write 4*(Sc+Si) + 4 (+12*(Sc+Si) positions).
+#include "common.hpp"
+#pragma clang fp contract(off)
+
+using namespace nerfhip;
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_scan_add(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// ATen row_sum over `count` items x[(r)*stride + k], r = 0..count-1 (aten/src/ATen/native/cpu/SumKernel.cpp:
+// 4 interleaved accumulators, each a 4-level cascade with level step >= 16).
+__device__ float cascade_row_sum(const float* x, int stride, int k, int count) {
+    const int size_ilp = count >> 2;
+    int clog = 0;
+    while ((1 << clog) < size_ilp) ++clog;
+    const int level_power = (clog / 4) > 4 ? (clog / 4) : 4;
+    const int level_step = 1 << level_power;
+    const int level_mask = level_step - 1;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+    int i = 0;
+    while (i + level_step <= size_ilp) {
+        for (int j = 0; j < level_step; ++j, ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[0][q] = acc[0][q] + x[(i * 4 + q) * stride + k];
+        }
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[j][q] = acc[j][q] + acc[j - 1][q]; acc[j - 1][q] = 0.0f; }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < size_ilp; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[0][q] = acc[0][q] + x[(i * 4 + q) * stride + k];
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[0][q] = acc[0][q] + acc[j][q];
+    for (int r = size_ilp * 4; r < count; ++r) acc[0][0] = acc[0][0] + x[r * stride + k];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) acc[0][0] = acc[0][0] + acc[0][q];
+    return acc[0][0];
+}
+
+__device__ __forceinline__ bool lt_nan_last(float a, float b) { return (a < b) || ((b != b) && (a == a)); }
+__device__ __forceinline__ bool eq_nan(float a, float b) { return (a == b) || ((a != a) && (b != b)); }
+
+__global__ void __launch_bounds__(WAVE * WAVES_PER_BLOCK)
+k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict__ z,
+              const float* __restrict__ weights, const float* __restrict__ u, int u_shared,
+              const float* __restrict__ rays, int ld,
+              float* __restrict__ z_out, float* __restrict__ pts_out, float* __restrict__ z_std,
+              float* __restrict__ samples, int64_t* __restrict__ inds_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int Sf = Sc + Si, nb = Sc - 1, nw = Sc - 2;
+    const int Sf4 = (Sf + 3) & ~3, nb4 = (nb + 3) & ~3;
+    float* zs = smem + (size_t)wv * (2 * Sf4 + 3 * nb4);  // merged (unsorted) depths
+    float* zsorted = zs + Sf4;
+    float* cdf = zsorted + Sf4;   // [nb]
+    float* bins = cdf + nb4;      // [nb]
+    float* wp = bins + nb4;       // [nw] weights + 1e-5, then pdf
+    const int64_t wave0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (int64_t ray = wave0; ray < n; ray += nwaves) {
+        // ---- stage inputs
+        if (bins_given) {  // stand-alone sample_pdf: z holds the nb bin edges, weights the nw = nb-1 bin weights
+            for (int s = lane; s < nb; s += 64) bins[s] = z[ray * nb + s];
+            for (int s = lane; s < nw; s += 64) wp[s] = weights[ray * nw + s] + 1e-5f;
+        } else {
+            for (int s = lane; s < Sc; s += 64) zs[s] = z[ray * Sc + s];
+            for (int s = lane; s < nw; s += 64) wp[s] = weights[ray * Sc + 1 + s] + 1e-5f;
+            __builtin_amdgcn_wave_barrier();
+            for (int s = lane; s < nb; s += 64) bins[s] = 0.5f * (zs[s + 1] + zs[s]);
+        }
+        // ---- sum of the weights in ATen's order
+        float total;
+        if (nw >= 8) {
+            const int vec = nw >> 3;
+            float part = 0.0f;
+            if (lane < 8) part = cascade_row_sum(wp, 8, lane, vec);
+            float fin = 0.0f;
+            for (int e = vec * 8; e < nw; ++e) fin = fin + wp[e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fin = fin + __shfl(part, k, 64);
+            total = fin;
+        } else {
+            total = cascade_row_sum(wp, 1, 0, nw);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- pdf and cdf
+        double carry = 0.0;
+        if (lane == 0) cdf[0] = 0.0f;
+        for (int s0 = 0; s0 < nw; s0 += 64) {
+            const int s = s0 + lane;
+            double p = 0.0;
+            if (s < nw) p = (double)(wp[s] / total);
+            const double incl = wave_scan_add(p, lane);
+            if (s < nw) cdf[s + 1] = (float)(carry + incl);
+            carry += __shfl(incl, 63, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- invert the cdf
+        double su = 0.0;
+        for (int j = lane; j < Si; j += 64) {
+            const float uj = u_shared ? u[j] : u[ray * Si + j];
+            int lo = 0, hi = nb;  // first index with cdf[idx] > uj
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] > uj) hi = mid; else lo = mid + 1;
+            }
+            const int below = lo - 1 > 0 ? lo - 1 : 0;
+            const int above = lo < nb - 1 ? lo : nb - 1;
+            const float cb = cdf[below], ca = cdf[above];
+            const float bb = bins[below], ba = bins[above];
+            float denom = ca - cb;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (uj - cb) / denom;
+            const float smp = bb + t * (ba - bb);
+            zs[Sc + j] = smp;
+            su += (double)smp;
+            if (samples) samples[ray * Si + j] = smp;
+            if (inds_out) inds_out[ray * Si + j] = (int64_t)lo;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- population standard deviation of the new samples
+        if (z_std) {
+            const double mean = wave_sum_d(su) / (double)Si;
+            double m2 = 0.0;
+            for (int j = lane; j < Si; j += 64) {
+                const double dv = (double)zs[Sc + j] - mean;
+                m2 += dv * dv;
+            }
+            m2 = wave_sum_d(m2);
+            if (lane == 0) z_std[ray] = (float)sqrt(m2 / (double)Si);
+        }
+        if (bins_given) { __builtin_amdgcn_wave_barrier(); continue; }
+        // ---- stable rank sort (NaN last) of the Sf depths
+        for (int e = lane; e < Sf; e += 64) {
+            const float v = zs[e];
+            int rank = 0;
+            for (int f = 0; f < Sf; ++f) {
+                const float o = zs[f];
+                rank += (lt_nan_last(o, v) || (f < e && eq_nan(o, v))) ? 1 : 0;
+            }
+            zsorted[rank] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int s = lane; s < Sf; s += 64) z_out[ray * Sf + s] = zsorted[s];
+        if (pts_out) {
+            const float* rr = rays + ray * ld;
+            const float ox = rr[0], oy = rr[1], oz = rr[2], dx = rr[3], dy = rr[4], dz = rr[5];
+            for (int e = lane; e < Sf * 3; e += 64) {
+                const int s = e / 3, c = e - s * 3;
+                const float zz = zsorted[s];
+                const float o = c == 0 ? ox : (c == 1 ? oy : oz);
+                const float d = c == 0 ? dx : (c == 1 ? dy : dz);
+                pts_out[ray * Sf * 3 + e] = o + d * zz;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nerf_sample_fine(int64_t n, int Sc, int Si, const float* z, const float* weights, const float* u, int u_shared,
+                     const float* rays, int ray_stride, float* z_out, float* pts_out, float* z_std, float* samples,
+                     int64_t* inds, void* stream) {
+    NERF_REQUIRE(n >= 0 && Sc >= 3 && Si >= 1, "nerf_sample_fine: n=%lld Sc=%d Si=%d (need Sc>=3, Si>=1)", (long long)n,
+                 Sc, Si);
+    if (n == 0) return 0;
+    NERF_REQUIRE(z && weights && u && z_out, "nerf_sample_fine: null pointer");
+    NERF_REQUIRE(!pts_out || (rays && ray_stride >= 6), "nerf_sample_fine: pts_out needs rays with stride >= 6");
+    const int Sf4 = (Sc + Si + 3) & ~3, nb4 = (Sc - 1 + 3) & ~3;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (2 * Sf4 + 3 * nb4) * sizeof(float);
+    NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_fine: Sc+Si=%d needs %zu bytes of LDS (> 160 KiB)", Sc + Si, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_sample_fine: LDS attribute: %s", hipGetErrorString(e));
+    }
+    int64_t g = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const int64_t cap = 256 * 8;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(k_sample_fine, dim3((int)g), dim3(WAVE * WAVES_PER_BLOCK), lds, as_stream(stream), n, Sc, Si, 0, z,
+                       weights, u, u_shared, rays, ray_stride, z_out, pts_out, z_std, samples, inds);
+    return launched("nerf_sample_fine");
+}
+
+int nerf_sample_pdf(int64_t n, int n_bins, int Si, const float* bins, const float* weights, const float* u,
+                    int u_shared, float* samples, int64_t* inds, void* stream) {
+    NERF_REQUIRE(n >= 0 && n_bins >= 2 && Si >= 1, "nerf_sample_pdf: n=%lld n_bins=%d Si=%d (need n_bins>=2, Si>=1)",
+                 (long long)n, n_bins, Si);
+    if (n == 0) return 0;
+    NERF_REQUIRE(bins && weights && u && samples, "nerf_sample_pdf: null pointer");
+    const int Sc = n_bins + 1;
+    const int Sf4 = (Sc + Si + 3) & ~3, nb4 = (n_bins + 3) & ~3;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (2 * Sf4 + 3 * nb4) * sizeof(float);
+    NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_pdf: n_bins+Si=%d needs %zu bytes of LDS (> 160 KiB)", n_bins + Si, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_sample_pdf: LDS attribute: %s", hipGetErrorString(e));
+    }
+    int64_t g = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const int64_t cap = 256 * 8;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(k_sample_fine, dim3((int)g), dim3(WAVE * WAVES_PER_BLOCK), lds, as_stream(stream), n, Sc, Si, 1,
+                       bins, weights, u, u_shared, nullptr, 0, nullptr, nullptr, nullptr, samples, inds);
+    return launched("nerf_sample_pdf");
+}
+
+}  // extern "C"

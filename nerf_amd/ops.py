@@ -1,0 +1,292 @@
+"""Tensor-level wrappers around the C-ABI kernels.
+
+PyTorch is used for device memory, the current HIP stream and autograd graph edges only; every
+number is produced by libnerf_hip.so.  All wrappers require fp32 tensors on a HIP device and raise
+if the library reports an error.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from ._lib import check, lib
+
+
+def device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("nerf_amd needs a HIP device: torch.cuda.is_available() is False and there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_dev(x, dtype=torch.float32) -> torch.Tensor:
+    """Host arrays / CPU tensors / other dtypes -> contiguous fp32 tensor on the current HIP device."""
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(x)
+    if not x.is_cuda:
+        x = x.to(device())
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    return x.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"{what}: expected an fp32 tensor on a HIP device, got {t.dtype} on {t.device}")
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# rays
+# ------------------------------------------------------------------------------------------------
+def get_rays(H: int, W: int, fx: float, fy: float, cx: float, cy: float, c2w: torch.Tensor):
+    c2w = _f32c(to_dev(c2w)[:3, :4], "c2w")
+    o = torch.empty((H, W, 3), dtype=torch.float32, device=c2w.device)
+    d = torch.empty_like(o)
+    with torch.cuda.device(c2w.device):
+        check(lib.nerf_get_rays(H, W, fx, fy, cx, cy, c2w.data_ptr(), o.data_ptr(), d.data_ptr(), _stream()))
+    return o, d
+
+
+def ndc_rays(sx: float, sy: float, near: float, rays_o: torch.Tensor, rays_d: torch.Tensor):
+    o, d = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d")
+    oo, od = torch.empty_like(o), torch.empty_like(d)
+    n = o.numel() // 3
+    with torch.cuda.device(o.device):
+        check(lib.nerf_ndc_rays(n, sx, sy, near, o.data_ptr(), d.data_ptr(), oo.data_ptr(), od.data_ptr(), _stream()))
+    return oo, od
+
+
+_LINSPACE = {}
+
+
+def cached_linspace(steps: int, dev) -> torch.Tensor:
+    """linspace(0, 1, steps) evaluated by the CPU kernel (the values the reference's CPU run uses) and kept on `dev`."""
+    key = (int(steps), str(dev))
+    t = _LINSPACE.get(key)
+    if t is None:
+        t = torch.linspace(0., 1., steps=int(steps), device="cpu").to(dev)
+        _LINSPACE[key] = t
+    return t
+
+
+def pack_rays(rays_o, rays_d, near, far, viewdir_src=None, ndc=None):
+    """-> [n, 8|11] ray records.  ndc = (sx, sy, near_plane) or None; near/far: floats or per-ray tensors."""
+    o = _f32c(rays_o.reshape(-1, 3), "rays_o")
+    d = _f32c(rays_d.reshape(-1, 3), "rays_d")
+    n = o.shape[0]
+    vd = None if viewdir_src is None else _f32c(viewdir_src.reshape(-1, 3), "viewdirs")
+    ld = 11 if vd is not None else 8
+    out = torch.empty((n, ld), dtype=torch.float32, device=o.device)
+
+    def bound(b):
+        if torch.is_tensor(b) and b.numel() > 1:
+            return 0.0, _f32c(to_dev(b).reshape(-1), "near/far").expand(n).contiguous()
+        return float(b), None
+    near_s, near_v = bound(near)
+    far_s, far_v = bound(far)
+    sx, sy, nn = ndc if ndc is not None else (0.0, 0.0, 0.0)
+    with torch.cuda.device(o.device):
+        check(lib.nerf_pack_rays(n, o.data_ptr(), d.data_ptr(), _ptr(vd), int(ndc is not None), sx, sy, nn, near_s, far_s,
+                                 _ptr(near_v), _ptr(far_v), out.data_ptr(), ld, _stream()))
+    return out
+
+
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, u: torch.Tensor, want_inds: bool = False):
+    bins, weights, u = _f32c(bins, "bins"), _f32c(weights, "weights"), _f32c(u, "u")
+    n, nb = bins.shape
+    assert weights.shape == (n, nb - 1), (bins.shape, weights.shape)
+    shared = u.dim() == 1
+    Si = u.shape[-1]
+    samples = torch.empty((n, Si), dtype=torch.float32, device=bins.device)
+    inds = torch.empty((n, Si), dtype=torch.int64, device=bins.device) if want_inds else None
+    with torch.cuda.device(bins.device):
+        check(lib.nerf_sample_pdf(n, nb, Si, bins.data_ptr(), weights.data_ptr(), u.data_ptr(), int(shared),
+                                  samples.data_ptr(), _ptr(inds), _stream()))
+    return (samples, inds) if want_inds else samples
+
+
+def sample_coarse(rays: torch.Tensor, t_vals: torch.Tensor, t_rand: Optional[torch.Tensor], lindisp: bool):
+    rays = _f32c(rays, "rays")
+    n, ld = rays.shape
+    S = t_vals.numel()
+    z = torch.empty((n, S), dtype=torch.float32, device=rays.device)
+    pts = torch.empty((n, S, 3), dtype=torch.float32, device=rays.device)
+    if t_rand is not None:
+        t_rand = _f32c(t_rand, "t_rand")
+        assert t_rand.shape == (n, S)
+    with torch.cuda.device(rays.device):
+        check(lib.nerf_sample_coarse(n, S, rays.data_ptr(), ld, _f32c(t_vals, "t_vals").data_ptr(), _ptr(t_rand),
+                                     int(bool(lindisp)), z.data_ptr(), pts.data_ptr(), _stream()))
+    return z, pts
+
+
+def encode(x: torch.Tensor, n_freq: int) -> torch.Tensor:
+    x = _f32c(x, "x")
+    assert x.shape[-1] == 3
+    out = torch.empty(x.shape[:-1] + (3 + 6 * n_freq,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.nerf_encode(x.numel() // 3, n_freq, x.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def sample_fine(z: torch.Tensor, weights: torch.Tensor, u: torch.Tensor, rays: Optional[torch.Tensor],
+                want_pts: bool = True, want_samples: bool = False, want_inds: bool = False):
+    """-> dict(z, pts, z_std, samples, inds).  u is [n, Si], or [Si] shared by all rays."""
+    z, weights, u = _f32c(z, "z"), _f32c(weights, "weights"), _f32c(u, "u")
+    n, Sc = z.shape
+    shared = u.dim() == 1
+    Si = u.shape[-1]
+    dev = z.device
+    out = {"z": torch.empty((n, Sc + Si), dtype=torch.float32, device=dev),
+           "z_std": torch.empty((n,), dtype=torch.float32, device=dev),
+           "pts": torch.empty((n, Sc + Si, 3), dtype=torch.float32, device=dev) if want_pts else None,
+           "samples": torch.empty((n, Si), dtype=torch.float32, device=dev) if want_samples else None,
+           "inds": torch.empty((n, Si), dtype=torch.int64, device=dev) if want_inds else None}
+    ld = 0
+    if want_pts:
+        rays = _f32c(rays, "rays")
+        ld = rays.shape[1]
+    with torch.cuda.device(dev):
+        check(lib.nerf_sample_fine(n, Sc, Si, z.data_ptr(), weights.data_ptr(), u.data_ptr(), int(shared),
+                                   _ptr(rays) if want_pts else None, ld, out["z"].data_ptr(), _ptr(out["pts"]),
+                                   out["z_std"].data_ptr(), _ptr(out["samples"]), _ptr(out["inds"]), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# compositing
+# ------------------------------------------------------------------------------------------------
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z, rays_d, noise, white_bkgd):
+        raw, z = _f32c(raw, "raw"), _f32c(z, "z")
+        n, S = z.shape
+        rays = rays_d
+        if not (rays.is_cuda and rays.dtype == torch.float32 and rays.dim() == 2 and rays.shape == (n, 3)
+                and rays.stride(1) == 1):
+            rays = _f32c(rays.reshape(n, 3), "rays_d")
+        assert raw.shape == (n, S, 4)
+        if noise is not None:
+            noise = _f32c(noise, "noise")
+            assert noise.shape == (n, S)
+        dev = raw.device
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        disp = torch.empty((n,), dtype=torch.float32, device=dev)
+        acc = torch.empty_like(disp)
+        depth = torch.empty_like(disp)
+        weights = torch.empty((n, S), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.nerf_composite_fwd(n, S, raw.data_ptr(), z.data_ptr(), rays.data_ptr(), rays.stride(0), _ptr(noise),
+                                         int(bool(white_bkgd)), rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(),
+                                         weights.data_ptr(), depth.data_ptr(), _stream()))
+        ctx.save_for_backward(raw, z, rays, noise, weights)
+        ctx.white = bool(white_bkgd)
+        return rgb, disp, acc, weights, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_weights, g_depth):
+        raw, z, rays, noise, weights = ctx.saved_tensors
+        n, S = z.shape
+        d_raw = torch.empty_like(raw)
+
+        def g(t):
+            return None if t is None else _f32c(t, "grad")
+        g_rgb, g_disp, g_acc, g_weights, g_depth = g(g_rgb), g(g_disp), g(g_acc), g(g_weights), g(g_depth)
+        with torch.cuda.device(raw.device):
+            check(lib.nerf_composite_bwd(n, S, raw.data_ptr(), z.data_ptr(), rays.data_ptr(), rays.stride(0), _ptr(noise),
+                                         int(ctx.white), weights.data_ptr(), _ptr(g_rgb), _ptr(g_disp), _ptr(g_acc),
+                                         _ptr(g_weights), _ptr(g_depth), d_raw.data_ptr(), _stream()))
+        return d_raw, None, None, None, None
+
+
+def composite(raw, z, rays_d, noise=None, white_bkgd=False):
+    """-> rgb_map, disp_map, acc_map, weights, depth_map; differentiable w.r.t. raw only.
+    rays_d: [n,3], any row stride (e.g. a column slice of the packed ray records)."""
+    return _Composite.apply(raw, z, rays_d, noise, white_bkgd)
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP
+# ------------------------------------------------------------------------------------------------
+def mlp_n_params(use_viewdirs: bool, output_ch: int) -> int:
+    return lib.nerf_mlp_n_params(int(use_viewdirs), output_ch)
+
+
+def pack_weights(flat: torch.Tensor, use_viewdirs: bool, output_ch: int, want_bwd: bool):
+    flat = _f32c(flat, "params")
+    assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
+    fwd = torch.empty(lib.nerf_mlp_packed_floats(int(use_viewdirs)), dtype=torch.float32, device=flat.device)
+    bwd = (torch.empty(lib.nerf_mlp_packed_bwd_floats(int(use_viewdirs)), dtype=torch.float32, device=flat.device)
+           if want_bwd else None)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_pack_weights(int(use_viewdirs), output_ch, flat.data_ptr(), fwd.data_ptr(), _ptr(bwd), _stream()))
+    return fwd, bwd
+
+
+def mlp_forward(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_fwd: torch.Tensor, use_viewdirs: bool,
+                output_ch: int, pts_per_ray: int, act: Optional[torch.Tensor] = None) -> torch.Tensor:
+    pts = _f32c(pts, "pts")
+    n_pts = pts.numel() // 3
+    out_ch = 4 if use_viewdirs else output_ch
+    out = torch.empty((n_pts, out_ch), dtype=torch.float32, device=pts.device)
+    if use_viewdirs:
+        viewdirs = _f32c(viewdirs, "viewdirs")
+        assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
+    with torch.cuda.device(pts.device):
+        check(lib.nerf_mlp_fwd(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
+                               int(use_viewdirs), output_ch, packed_fwd.data_ptr(), out.data_ptr(), _ptr(act), _stream()))
+    return out
+
+
+def mlp_act_buffer(n_pts: int, use_viewdirs: bool, dev) -> torch.Tensor:
+    return torch.empty(lib.nerf_mlp_act_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=dev)
+
+
+def mlp_backward(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_bwd: torch.Tensor,
+                 packed_fwd: torch.Tensor, use_viewdirs: bool, output_ch: int, pts_per_ray: int) -> torch.Tensor:
+    d_out = _f32c(d_out, "d_out")
+    n_pts = d_out.shape[0]
+    scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
+    d_flat = torch.empty_like(flat)
+    with torch.cuda.device(d_out.device):
+        check(lib.nerf_mlp_bwd(n_pts, pts_per_ray, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
+                               packed_fwd.data_ptr(), packed_bwd.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(), _stream()))
+    return d_flat
+
+
+class _FusedMLP(torch.autograd.Function):
+    """raw = NeRF(encode(pts), encode(viewdirs)); gradients flow to the parameters only."""
+
+    @staticmethod
+    def forward(ctx, pts, viewdirs, model, pts_per_ray, *params):
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        fwd, bwd, flat = model._packed(need_grad)
+        n_pts = pts.numel() // 3
+        act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
+        out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
+        if need_grad:
+            ctx.save_for_backward(act, fwd, bwd, flat)
+            ctx.model = model
+            ctx.pts_per_ray = pts_per_ray
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        act, fwd, bwd, flat = ctx.saved_tensors
+        model = ctx.model
+        d_flat = mlp_backward(d_out, act, flat, bwd, fwd, model.use_viewdirs, model.output_ch, ctx.pts_per_ray)
+        grads = model._split_flat(d_flat)
+        return (None, None, None, None) + tuple(grads)
+
+
+def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_per_ray: int) -> torch.Tensor:
+    return _FusedMLP.apply(pts, viewdirs, model, pts_per_ray, *model.parameters())

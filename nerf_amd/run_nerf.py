@@ -1,0 +1,361 @@
+"""Drop-in for the render path of the upstream run_nerf.py (render / batchify_rays / render_rays /
+raw2outputs / run_network / create_nerf / render_path / config_parser): same signatures, keyword
+names, return structure and checkpoint layout; the arithmetic runs in libnerf_hip.so.
+Citations are file:line of the upstream tree."""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .run_nerf_helpers import *  # noqa: F401,F403  (upstream does the same, run_nerf.py:14)
+from .run_nerf_helpers import NeRF, get_embedder, get_rays
+
+DEBUG = False
+
+
+def batchify(fn, chunk):
+    """run_nerf.py:28-38."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """run_nerf.py:40-66.  With the module's own NeRF and embedders the encoding, the concatenation and
+    every layer run as ONE fused kernel over all points; netchunk (a memory knob upstream) then has
+    nothing to bound.  Any other `fn` gets the encoded features in netchunk slices, as upstream."""
+    fused = (isinstance(fn, NeRF) and getattr(embed_fn, 'n_freq', None) == 10
+             and (viewdirs is None or getattr(embeddirs_fn, 'n_freq', None) == 4)
+             and fn.use_viewdirs == (viewdirs is not None))
+    if fused:
+        pts = ops.to_dev(inputs)
+        S = int(np.prod(pts.shape[1:-1])) if pts.dim() > 2 else 1
+        out = fn.query(pts, None if viewdirs is None else ops.to_dev(viewdirs), S)
+        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape)
+        input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
+        embedded = torch.cat([embedded, embeddirs_fn(input_dirs_flat)], -1)
+    outputs_flat = batchify(fn, netchunk)(embedded)
+    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """run_nerf.py:71-85."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            if k not in all_ret:
+                all_ret[k] = []
+            all_ret[k].append(ret[k])
+    all_ret = {k: torch.cat(all_ret[k], 0) for k in all_ret}
+    return all_ret
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """run_nerf.py:87-160.  Returns [rgb_map, disp_map, acc_map, extras]."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+        rays_o, rays_d = ops.to_dev(rays_o), ops.to_dev(rays_d)
+
+    viewdir_src = None
+    if use_viewdirs:
+        viewdir_src = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+
+    sh = rays_d.shape
+    ndc_par = None
+    if ndc:
+        focal = K[0][0]
+        ndc_par = (float(-1. / (W / (2. * focal))), float(-1. / (H / (2. * focal))), 1.0)
+    rays = ops.pack_rays(rays_o, rays_d, near, far, viewdir_src, ndc_par)
+
+    all_ret = batchify_rays(rays, chunk, **kwargs)
+    for k in all_ret:
+        k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])
+        all_ret[k] = torch.reshape(all_ret[k], k_sh)
+
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """run_nerf.py:163-201.  PNG writing needs imageio, which is imported only when savedir is given."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H = H // render_factor
+        W = W // render_factor
+        focal = focal / render_factor
+
+    rgbs, disps = [], []
+    t = time.time()
+    for i, c2w in enumerate(render_poses):
+        print(i, time.time() - t)
+        t = time.time()
+        rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        if i == 0:
+            print(rgb.shape, disp.shape)
+        if savedir is not None:
+            import imageio
+            imageio.imwrite(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))  # noqa: F405
+    return np.stack(rgbs, 0), np.stack(disps, 0)
+
+
+def create_nerf(args):
+    """run_nerf.py:204-289: models, query function, Adam, checkpoint reload, render kwargs."""
+    dev = ops.device()
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views = 0
+    embeddirs_fn = None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(dev)
+    grad_vars = list(model.parameters())
+
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(dev)
+        grad_vars += list(model_fine.parameters())
+
+    network_query_fn = lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn,
+                                                                        embed_fn=embed_fn,
+                                                                        embeddirs_fn=embeddirs_fn,
+                                                                        netchunk=args.netchunk)
+
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+
+    start = 0
+    basedir = args.basedir
+    expname = args.expname
+
+    if args.ft_path is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        ckpts = [os.path.join(basedir, expname, f) for f in sorted(os.listdir(os.path.join(basedir, expname)))
+                 if 'tar' in f]
+
+    print('Found ckpts', ckpts)
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt_path = ckpts[-1]
+        print('Reloading from', ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location=dev)
+        start = ckpt['global_step']
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        model.load_state_dict(ckpt['network_fn_state_dict'])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn,
+        'perturb': args.perturb,
+        'N_importance': args.N_importance,
+        'network_fine': model_fine,
+        'N_samples': args.N_samples,
+        'network_fn': model,
+        'use_viewdirs': args.use_viewdirs,
+        'white_bkgd': args.white_bkgd,
+        'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        print('Not ndc!')
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+
+
+def save_checkpoint(path, global_step, render_kwargs_train, optimizer):
+    """The checkpoint dict of the upstream train loop (run_nerf.py:890-898)."""
+    torch.save({
+        'global_step': global_step,
+        'network_fn_state_dict': render_kwargs_train['network_fn'].state_dict(),
+        'network_fine_state_dict': render_kwargs_train['network_fine'].state_dict(),
+        'optimizer_state_dict': optimizer.state_dict(),
+    }, path)
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """run_nerf.py:292-362 -> rgb_map, disp_map, acc_map, weights, depth_map."""
+    raw, z_vals = ops.to_dev(raw), ops.to_dev(z_vals)
+    if not (torch.is_tensor(rays_d) and rays_d.is_cuda and rays_d.dtype == torch.float32):
+        rays_d = ops.to_dev(rays_d)
+    noise = None
+    if raw_noise_std > 0.:
+        if pytest:
+            np.random.seed(0)
+            noise = torch.Tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std).to(raw.device)
+        else:
+            noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std
+    return ops.composite(raw, z_vals, rays_d, noise, white_bkgd)
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False):
+    """run_nerf.py:366-491."""
+    ray_batch = ops.to_dev(ray_batch)
+    N_rays = ray_batch.shape[0]
+    dev = ray_batch.device
+    rays_d = ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
+
+    t_vals = ops.cached_linspace(N_samples, dev)
+    t_rand = None
+    if perturb > 0.:
+        if pytest:
+            np.random.seed(0)
+            t_rand = torch.Tensor(np.random.rand(N_rays, N_samples)).to(dev)
+        else:
+            t_rand = torch.rand(N_rays, N_samples, device=dev)
+    z_vals, pts = ops.sample_coarse(ray_batch, t_vals, t_rand, lindisp)
+
+    raw = network_query_fn(pts, viewdirs, network_fn)
+    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd,
+                                                                 pytest=pytest)
+
+    if N_importance > 0:
+        rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
+        if pytest:
+            np.random.seed(0)
+            if perturb == 0.:
+                u = torch.Tensor(np.linspace(0., 1., N_importance)).to(dev)
+            else:
+                u = torch.Tensor(np.random.rand(N_rays, N_importance)).to(dev)
+        elif perturb == 0.:
+            u = ops.cached_linspace(N_importance, dev)
+        else:
+            u = torch.rand(N_rays, N_importance, device=dev)
+        fine = ops.sample_fine(z_vals, weights.detach(), u, ray_batch)
+        z_vals, pts = fine["z"], fine["pts"]
+
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd,
+                                                                     pytest=pytest)
+
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if retraw:
+        ret['raw'] = raw
+    if N_importance > 0:
+        ret['rgb0'] = rgb_map_0
+        ret['disp0'] = disp_map_0
+        ret['acc0'] = acc_map_0
+        ret['z_std'] = fine["z_std"]
+
+    if DEBUG:
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+# ------------------------------------------------------------------------------------------------
+# flags (run_nerf.py:494-604).  configargparse is not a dependency here: --config names a file of
+# `key = value` lines whose entries act as defaults that the command line overrides.
+# ------------------------------------------------------------------------------------------------
+class _ConfigParser(argparse.ArgumentParser):
+    def parse_known_args(self, args=None, namespace=None):
+        import sys
+        argv = list(sys.argv[1:] if args is None else args)
+        cfg = None
+        for i, a in enumerate(argv):
+            if a == '--config' and i + 1 < len(argv):
+                cfg = argv[i + 1]
+            elif a.startswith('--config='):
+                cfg = a.split('=', 1)[1]
+        file_args = []
+        if cfg is not None:
+            with open(cfg, 'r') as fh:
+                for line in fh:
+                    line = line.split('#', 1)[0].strip()
+                    if not line or '=' not in line:
+                        continue
+                    key, val = [s.strip() for s in line.split('=', 1)]
+                    action = next((a for a in self._actions if ('--' + key) in a.option_strings), None)
+                    if action is None:
+                        raise SystemExit(f"unknown option '{key}' in {cfg}")
+                    if isinstance(action, argparse._StoreTrueAction):
+                        if val.lower() in ('true', '1', 'yes'):
+                            file_args.append('--' + key)
+                    else:
+                        file_args += ['--' + key, val]
+        return super().parse_known_args(file_args + argv, namespace)
+
+
+def config_parser():
+    parser = _ConfigParser()
+    parser.add_argument('--config', type=str, default=None, help='config file path')
+    parser.add_argument("--expname", type=str, help='experiment name')
+    parser.add_argument("--basedir", type=str, default='./logs/', help='where to store ckpts and logs')
+    parser.add_argument("--datadir", type=str, default='./data/llff/fern', help='input data directory')
+    # training options
+    parser.add_argument("--netdepth", type=int, default=8, help='layers in network')
+    parser.add_argument("--netwidth", type=int, default=256, help='channels per layer')
+    parser.add_argument("--netdepth_fine", type=int, default=8, help='layers in fine network')
+    parser.add_argument("--netwidth_fine", type=int, default=256, help='channels per layer in fine network')
+    parser.add_argument("--N_rand", type=int, default=32 * 32 * 4, help='batch size (number of random rays per gradient step)')
+    parser.add_argument("--lrate", type=float, default=5e-4, help='learning rate')
+    parser.add_argument("--lrate_decay", type=int, default=250, help='exponential learning rate decay (in 1000 steps)')
+    parser.add_argument("--chunk", type=int, default=1024 * 32, help='number of rays processed in parallel')
+    parser.add_argument("--netchunk", type=int, default=1024 * 64, help='number of pts sent through network in parallel')
+    parser.add_argument("--no_batching", action='store_true', help='only take random rays from 1 image at a time')
+    parser.add_argument("--no_reload", action='store_true', help='do not reload weights from saved ckpt')
+    parser.add_argument("--ft_path", type=str, default=None, help='specific weights file to reload for coarse network')
+    # rendering options
+    parser.add_argument("--N_samples", type=int, default=64, help='number of coarse samples per ray')
+    parser.add_argument("--N_importance", type=int, default=0, help='number of additional fine samples per ray')
+    parser.add_argument("--perturb", type=float, default=1., help='set to 0. for no jitter, 1. for jitter')
+    parser.add_argument("--use_viewdirs", action='store_true', help='use full 5D input instead of 3D')
+    parser.add_argument("--i_embed", type=int, default=0, help='set 0 for default positional encoding, -1 for none')
+    parser.add_argument("--multires", type=int, default=10, help='log2 of max freq for positional encoding (3D location)')
+    parser.add_argument("--multires_views", type=int, default=4, help='log2 of max freq for positional encoding (2D direction)')
+    parser.add_argument("--raw_noise_std", type=float, default=0., help='std dev of noise added to regularize sigma_a output')
+    parser.add_argument("--render_only", action='store_true', help='do not optimize, reload weights and render out render_poses path')
+    parser.add_argument("--render_test", action='store_true', help='render the test set instead of render_poses path')
+    parser.add_argument("--render_factor", type=int, default=0, help='downsampling factor to speed up rendering')
+    # training options
+    parser.add_argument("--precrop_iters", type=int, default=0, help='number of steps to train on central crops')
+    parser.add_argument("--precrop_frac", type=float, default=.5, help='fraction of img taken for central crops')
+    # dataset options
+    parser.add_argument("--dataset_type", type=str, default='llff', help='options: llff / blender / deepvoxels')
+    parser.add_argument("--testskip", type=int, default=8, help='will load 1/N images from test/val sets')
+    parser.add_argument("--shape", type=str, default='greek', help='options : armchair / cube / greek / vase')
+    parser.add_argument("--white_bkgd", action='store_true', help='set to render synthetic data on a white bkgd')
+    parser.add_argument("--half_res", action='store_true', help='load blender synthetic data at 400x400 instead of 800x800')
+    parser.add_argument("--factor", type=int, default=8, help='downsample factor for LLFF images')
+    parser.add_argument("--no_ndc", action='store_true', help='do not use normalized device coordinates')
+    parser.add_argument("--lindisp", action='store_true', help='sampling linearly in disparity rather than depth')
+    parser.add_argument("--spherify", action='store_true', help='set for spherical 360 scenes')
+    parser.add_argument("--llffhold", type=int, default=8, help='will take every 1/N images as LLFF test set')
+    # logging/saving options
+    parser.add_argument("--i_print", type=int, default=100, help='frequency of console printout and metric loggin')
+    parser.add_argument("--i_img", type=int, default=500, help='frequency of tensorboard image logging')
+    parser.add_argument("--i_weights", type=int, default=10000, help='frequency of weight ckpt saving')
+    parser.add_argument("--i_testset", type=int, default=50000, help='frequency of testset saving')
+    parser.add_argument("--i_video", type=int, default=50000, help='frequency of render_poses video saving')
+    return parser

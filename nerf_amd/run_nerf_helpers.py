@@ -1,0 +1,191 @@
+"""Drop-in for the upstream run_nerf_helpers.py: same names, arguments and results, computed by the
+HIP kernels of libnerf_hip.so.  Citations are file:line of the upstream tree."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+# Misc (run_nerf_helpers.py:8-10) -- the train-step tail stays in PyTorch.
+img2mse = lambda x, y: torch.mean((x - y) ** 2)
+mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# Positional encoding (run_nerf_helpers.py:13-66)
+# ------------------------------------------------------------------------------------------------
+class Embedder:
+    """[x, sin(2^k x), cos(2^k x)]_{k<L}.  Only the upstream default configuration exists in kernel
+    form (include_input, log-spaced powers of two, sin then cos, 3 input dims)."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        self.create_embedding_fn()
+
+    def create_embedding_fn(self):
+        kw = self.kwargs
+        fns = list(kw.get('periodic_fns', [torch.sin, torch.cos]))
+        standard = (kw.get('include_input', True) and kw.get('input_dims', 3) == 3 and kw.get('log_sampling', True)
+                    and fns == [torch.sin, torch.cos] and kw['max_freq_log2'] == kw['num_freqs'] - 1)
+        if not standard:
+            raise NotImplementedError("Embedder: only include_input / 3 dims / log_sampling / [sin, cos] / "
+                                      "max_freq_log2 == num_freqs-1 is implemented in the HIP kernels")
+        self.n_freq = int(kw['num_freqs'])
+        self.out_dim = 3 + 6 * self.n_freq
+
+    def embed(self, inputs):
+        return ops.encode(ops.to_dev(inputs), self.n_freq)
+
+
+class _EmbedFn:
+    """The callable get_embedder returns; carries n_freq so that run_network can fuse it into the MLP kernel."""
+
+    def __init__(self, embedder: Embedder):
+        self.embedder = embedder
+        self.n_freq = embedder.n_freq
+
+    def __call__(self, x):
+        return self.embedder.embed(x)
+
+
+def get_embedder(multires, i=0):
+    if i == -1:
+        return nn.Identity(), 3
+    embedder_obj = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                            log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    return _EmbedFn(embedder_obj), embedder_obj.out_dim
+
+
+# ------------------------------------------------------------------------------------------------
+# Model (run_nerf_helpers.py:73-133)
+# ------------------------------------------------------------------------------------------------
+class NeRF(nn.Module):
+    """Same constructor, attributes and state_dict as upstream; forward runs the fused MFMA kernel.
+
+    The kernel exists for the architecture every upstream config uses: D=8, W=256, skips=[4],
+    input_ch=63 (L=10), input_ch_views=27 (L=4) or no view branch.  Other shapes raise."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        super(NeRF, self).__init__()
+        self.D = D
+        self.W = W
+        self.input_ch = input_ch
+        self.input_ch_views = input_ch_views
+        self.skips = skips
+        self.use_viewdirs = use_viewdirs
+        self.output_ch = output_ch
+
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] + [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + input_ch, W)
+                                        for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+        self._pack_key = None
+        self._pack = None
+
+    # -- kernel plumbing ---------------------------------------------------------------------------
+    def _check_arch(self):
+        ok = (self.D == 8 and self.W == 256 and list(self.skips) == [4] and self.input_ch == 63
+              and ((self.use_viewdirs and self.input_ch_views == 27) or
+                   (not self.use_viewdirs and self.input_ch_views == 0 and 1 <= self.output_ch <= 8)))
+        if not ok:
+            raise NotImplementedError(
+                f"NeRF(D={self.D}, W={self.W}, skips={self.skips}, input_ch={self.input_ch}, "
+                f"input_ch_views={self.input_ch_views}, use_viewdirs={self.use_viewdirs}): the fused HIP kernel "
+                "implements D=8, W=256, skips=[4], input_ch=63 and input_ch_views=27 (or 0 without view directions)")
+
+    def _packed(self, want_bwd: bool):
+        """(forward stream, backward stream or None, flat parameters); repacked when a parameter changed."""
+        self._check_arch()
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._pack is None or self._pack_key != key or (want_bwd and self._pack[1] is None):
+            with torch.no_grad():
+                flat = torch.cat([p.detach().reshape(-1) for p in params])
+                if not flat.is_cuda:
+                    raise RuntimeError("NeRF parameters must live on a HIP device (call .to('cuda'))")
+                fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd)
+            self._pack, self._pack_key = (fwd, bwd, flat), key
+        return self._pack
+
+    def _split_flat(self, flat: torch.Tensor):
+        out, off = [], 0
+        for p in self.parameters():
+            out.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out
+
+    def query(self, pts: torch.Tensor, viewdirs, pts_per_ray: int) -> torch.Tensor:
+        """Fused encode + forward on raw positions [P,3] and per-ray unit directions [R,3]."""
+        return ops.fused_mlp(pts, viewdirs if self.use_viewdirs else None, self, pts_per_ray)
+
+    def forward(self, x):
+        """x: already-encoded inputs [..., input_ch + input_ch_views], as upstream."""
+        raise NotImplementedError("NeRF.forward on pre-encoded inputs: use run_network / NeRF.query, which fuse the "
+                                  "encoding into the kernel")
+
+    def load_weights_from_keras(self, weights):
+        """run_nerf_helpers.py:136-163."""
+        assert self.use_viewdirs, "Not implemented if use_viewdirs=False"
+        dev = self.alpha_linear.weight.device
+
+        def put(lin, iw):
+            lin.weight.data = torch.from_numpy(np.transpose(weights[iw])).to(dev)
+            lin.bias.data = torch.from_numpy(np.transpose(weights[iw + 1])).to(dev)
+        for i in range(self.D):
+            put(self.pts_linears[i], 2 * i)
+        put(self.feature_linear, 2 * self.D)
+        put(self.views_linears[0], 2 * self.D + 2)
+        put(self.rgb_linear, 2 * self.D + 4)
+        put(self.alpha_linear, 2 * self.D + 6)
+
+
+# ------------------------------------------------------------------------------------------------
+# Ray helpers (run_nerf_helpers.py:169-255)
+# ------------------------------------------------------------------------------------------------
+def get_rays(H, W, K, c2w):
+    return ops.get_rays(int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), c2w)
+
+
+def get_rays_np(H, W, K, c2w):
+    """Host-side float64 rays used once at start-up to precompute training rays (run_nerf_helpers.py:217-226)."""
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    dirs = np.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -np.ones_like(i)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    rays_o = np.broadcast_to(c2w[:3, -1], np.shape(rays_d))
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    sx = -1. / (W / (2. * focal))
+    sy = -1. / (H / (2. * focal))
+    return ops.ndc_rays(float(sx), float(sy), float(near), ops.to_dev(rays_o), ops.to_dev(rays_d))
+
+
+# ------------------------------------------------------------------------------------------------
+# Hierarchical sampling (run_nerf_helpers.py:260-303)
+# ------------------------------------------------------------------------------------------------
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    bins, weights = ops.to_dev(bins), ops.to_dev(weights)
+    lead = bins.shape[:-1]
+    bins2, w2 = bins.reshape(-1, bins.shape[-1]), weights.reshape(-1, weights.shape[-1])
+    n = bins2.shape[0]
+    if pytest:
+        np.random.seed(0)
+        if det:
+            u = torch.Tensor(np.linspace(0., 1., N_samples)).to(bins.device)
+        else:
+            u = torch.Tensor(np.random.rand(*(list(lead) + [N_samples]))).to(bins.device).reshape(n, N_samples)
+    elif det:
+        u = ops.cached_linspace(N_samples, bins.device)
+    else:
+        u = torch.rand(n, N_samples, device=bins.device)
+    return ops.sample_pdf(bins2, w2, u).reshape(list(lead) + [N_samples])

@@ -1,0 +1,341 @@
+"""HIP path vs the CPU oracle and vs the committed reference outputs (tests/golden).
+
+Tolerances (fp32 path): elementwise kernels with no libm call are bit-exact; kernels that call
+exp/sin/cos differ from the CPU libm by a few ulp; the MLP differs by fp32 summation order
+(MFMA k-order vs the CPU GEMM), |d| <= 2e-5 * max(1, |x|) on the raw outputs for these weights;
+composited maps inherit that.  sample_pdf indices are exact given identical cdf inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(got, want, rtol, atol, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, equal_nan=True, err_msg=what)
+
+
+def exact(got, want, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} differ, max|d|={np.nanmax(np.abs(got - want))}"
+
+
+def _peaky(sd, gain):
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["alpha_linear.weight"] *= gain
+    sd["alpha_linear.bias"] = sd["alpha_linear.bias"] * gain + 0.5
+    return sd
+
+
+def _model(sd, device, use_viewdirs=True, output_ch=5):
+    from nerf_amd.run_nerf_helpers import NeRF
+    m = NeRF(D=8, W=256, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=output_ch, skips=[4],
+             use_viewdirs=use_viewdirs)
+    m.load_state_dict(sd)
+    return m.to(device)
+
+
+def _query_fn():
+    from nerf_amd.run_nerf import run_network
+    from nerf_amd.run_nerf_helpers import get_embedder
+    e, _ = get_embedder(10, 0)
+    ed, _ = get_embedder(4, 0)
+    return lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=e, embeddirs_fn=ed, netchunk=1 << 16)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_device_is_gfx950(device):
+    from nerf_amd._lib import lib, check
+    check(lib.nerf_check_device())
+
+
+def test_get_rays_and_ndc(device):
+    from nerf_amd.run_nerf_helpers import get_rays, ndc_rays
+    g = golden("rays")
+    for name in ("lego_half", "lego_full", "fern"):
+        H, W, focal = g[name + "_hwf"]
+        H, W = int(H), int(W)
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        pose = T(g[name + "_pose"])
+        pick = g[name + "_pick"]
+        o, d = get_rays(H, W, K, pose.to(device))
+        assert o.shape == (H, W, 3) and d.is_cuda
+        exact(d.reshape(-1, 3)[pick], g[name + "_d"], name + " rays_d vs reference")
+        oo, od = O.pixel_rays(H, W, K, pose)
+        exact(d, od, name + " rays_d vs oracle")
+        exact(o, oo, name + " rays_o vs oracle")
+        if name == "fern":
+            no, nd = ndc_rays(H, W, K[0][0], 1.0, o, d)
+            exact(no.reshape(-1, 3)[pick], g["fern_ndc_o"], "ndc o")
+            exact(nd.reshape(-1, 3)[pick], g["fern_ndc_d"], "ndc d")
+
+
+def test_encode(device):
+    from nerf_amd.run_nerf_helpers import get_embedder
+    g = golden("encode")
+    x = T(g["x"]).to(device)
+    for L in (10, 4):
+        fn, width = get_embedder(L, 0)
+        e = fn(x)
+        assert e.shape == (256, width)
+        # sin/cos of arguments up to 512*6: the device libm and the CPU one are both accurate to ~1 ulp
+        close(e, g[f"enc{L}"], 0, 4e-7, f"encode L={L}")
+        exact(e[:, :3], g["x"], "identity columns")
+
+
+def test_sample_coarse_bit_exact(device):
+    from nerf_amd import ops
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 300
+    rays = T(rng.normal(size=(n, 11)).astype(np.float32))
+    rays[:, 6] = T(rng.uniform(0.5, 2.0, size=n).astype(np.float32))
+    rays[:, 7] = rays[:, 6] + T(rng.uniform(1.0, 4.0, size=n).astype(np.float32))
+    for S in (64, 7, 256, 1):
+        t_rand = T(rng.uniform(size=(n, S)).astype(np.float32))
+        for lindisp in (False, True):
+            for tr in (None, t_rand):
+                z, pts = ops.sample_coarse(rays.to(device), ops.cached_linspace(S, device), None if tr is None else tr.to(device), lindisp)
+                zo = O.coarse_depths(rays[:, 6:7], rays[:, 7:8], S, lindisp, tr)
+                exact(z, zo, f"z S={S} lindisp={lindisp} perturb={tr is not None}")
+                po = rays[:, None, 0:3] + rays[:, None, 3:6] * zo[..., None]
+                exact(pts, po, "pts")
+
+
+def test_composite_forward_backward(device):
+    from nerf_amd.run_nerf import raw2outputs
+    from nerf_amd import ops
+    g = golden("composite")
+    z, d, noise = T(g["z"]), T(g["rays_d"]), T(g["noise"])
+    names = ("rgb", "disp", "acc", "weights", "depth")
+    for name in ("soft", "peaky", "edge"):
+        for white in (0, 1):
+            for noisy in (0, 1):
+                key = f"{name}_w{white}_n{noisy}"
+                raw = T(g[name + "_raw"]).to(device).requires_grad_(True)
+                out = ops.composite(raw, z.to(device), d.to(device), noise.to(device) if noisy else None, bool(white))
+                for t, nm in zip(out, names):
+                    # disparity = 1/max(1e-10, depth/acc) amplifies relative error; everything else is O(1)
+                    close(t, g[f"{key}_{nm}"], 2e-5 if nm != "disp" else 2e-4, 2e-6, f"{key} {nm}")
+                (out[0] * T(g[key + "_G"]).to(device)).sum().backward()
+                want = g[key + "_draw"]
+                scale = max(1.0, float(np.abs(want).max()))
+                close(raw.grad, want, 2e-4, 2e-6 * scale, key + " d_raw")
+    # the public wrapper, no noise, [n,3] directions with a row stride (a slice of a ray record)
+    rec = torch.zeros(z.shape[0], 11, device=device)
+    rec[:, 3:6] = d.to(device)
+    out = raw2outputs(T(g["soft_raw"]).to(device), z.to(device), rec[:, 3:6], 0, True)
+    close(out[0], g["soft_w1_n0_rgb"], 2e-5, 2e-6, "strided rays_d")
+    e = raw2outputs(T(g["edge_raw"]).to(device), z.to(device), d.to(device))
+    assert e[2][0].item() == 0.0 and np.isnan(e[1][0].item())
+
+
+def test_composite_all_gradients_and_long_rays(device):
+    """Upstream grads on every output, S spanning several 64-sample tiles, against autograd on the oracle."""
+    from nerf_amd import ops
+    rng = np.random.Generator(np.random.PCG64(6))
+    for S in (192, 65, 700):
+        n = 40
+        raw = T(rng.normal(scale=2.0, size=(n, S, 4)).astype(np.float32))
+        z = T(np.sort(rng.uniform(2, 6, size=(n, S)), -1).astype(np.float32))
+        d = T(rng.normal(size=(n, 3)).astype(np.float32))
+        G = [T(rng.normal(size=s).astype(np.float32)) for s in ((n, 3), (n,), (n,), (n, S), (n,))]
+        ro = raw.clone().requires_grad_(True)
+        oo = O.composite(ro, z, d, None, True)
+        sum((a * b).sum() for a, b in zip(oo, G)).backward()
+        rg = raw.to(device).requires_grad_(True)
+        og = ops.composite(rg, z.to(device), d.to(device), None, True)
+        sum((a * b.to(device)).sum() for a, b in zip(og, G)).backward()
+        for a, b, nm in zip(og, oo, ("rgb", "disp", "acc", "weights", "depth")):
+            close(a, b, 3e-5 if nm != "disp" else 3e-4, 3e-6, f"S={S} {nm}")
+        scale = float(ro.grad.abs().max())
+        close(rg.grad, ro.grad, 5e-4, 5e-6 * scale, f"S={S} d_raw")
+
+
+def _index_mismatches_are_ulp_ties(inds, want, u, bins, weights):
+    """Every index that differs from the reference must sit on a cdf value within 1 ulp of its uniform."""
+    bad = np.argwhere(inds != want)
+    if len(bad) == 0:
+        return 0
+    w = weights + np.float32(1e-5)
+    cdf = np.concatenate([np.zeros((w.shape[0], 1), np.float32),
+                          np.cumsum((w / w.sum(-1, keepdims=True, dtype=np.float64)).astype(np.float32), -1, dtype=np.float64).astype(np.float32)], -1)
+    for r, j in bad:
+        k = min(inds[r, j], want[r, j])
+        assert abs(int(inds[r, j]) - int(want[r, j])) == 1
+        assert abs(cdf[r, k] - u[r, j]) <= 2 * np.spacing(np.float32(u[r, j])), (r, j, cdf[r, k], u[r, j])
+    return len(bad)
+
+
+def test_sample_pdf_indices_exact(device):
+    from nerf_amd import ops
+    g = golden("sample_pdf")
+    for bk, wk, uk, sk, ik in (("bins", "weights", "u", "samples", "inds"), ("bins5", "weights5", "u5", "samples5", "inds5")):
+        s, inds = ops.sample_pdf(T(g[bk]).to(device), T(g[wk]).to(device), T(g[uk]).to(device), want_inds=True)
+        exact(inds, g[ik], ik + " vs reference")
+        close(s, g[sk], 2e-6, 2e-7, sk)
+    n, ns = g["u"].shape
+    s, inds = ops.sample_pdf(T(g["bins"]).to(device), T(g["weights"]).to(device), ops.cached_linspace(ns, device), want_inds=True)
+    exact(inds, g["inds_det"], "det inds")
+    close(s, g["samples_det"], 2e-6, 2e-7, "det samples")
+
+
+def test_sample_pdf_indices_exact_at_scale(device):
+    """512K uniforms against the oracle on this host: indices identical (ulp ties, if any, are proven to be ties)."""
+    from nerf_amd import ops
+    rng = np.random.Generator(np.random.PCG64(7))
+    n, nb, ns = 4096, 63, 128
+    bins = np.sort(rng.uniform(2, 6, size=(n, nb)), -1).astype(np.float32)
+    w = (rng.uniform(0, 1, size=(n, nb - 1)) ** 6).astype(np.float32)
+    u = rng.uniform(0, 1, size=(n, ns)).astype(np.float32)
+    so, io = O.inverse_cdf(T(bins), T(w), T(u), return_inds=True)
+    sg, ig = ops.sample_pdf(T(bins).to(device), T(w).to(device), T(u).to(device), want_inds=True)
+    n_ties = _index_mismatches_are_ulp_ties(ig.cpu().numpy(), io.numpy(), u, bins, w)
+    assert n_ties <= 2, n_ties
+    close(sg, so, 1e-5, 1e-6, "samples")
+    from nerf_amd.run_nerf_helpers import sample_pdf
+    s2 = sample_pdf(T(bins[:16]).to(device), T(w[:16]).to(device), 32, det=True)
+    exact(s2, O.inverse_cdf(T(bins[:16]), T(w[:16]), O.det_uniforms(16, 32)), "public sample_pdf det")
+    s3 = sample_pdf(T(bins[:16]).to(device), T(w[:16]).to(device), 32, det=False, pytest=True)
+    np.random.seed(0)
+    exact(s3, O.inverse_cdf(T(bins[:16]), T(w[:16]), torch.Tensor(np.random.rand(16, 32))), "public sample_pdf pytest")
+
+
+def test_sample_fine_merge_sort_std(device):
+    from nerf_amd import ops
+    rng = np.random.Generator(np.random.PCG64(8))
+    for Sc, Si in ((64, 128), (64, 64), (256, 512), (9, 5), (3, 1)):
+        n = 64
+        rays = T(rng.normal(size=(n, 11)).astype(np.float32))
+        z = T(np.sort(rng.uniform(2, 6, size=(n, Sc)), -1).astype(np.float32))
+        w = T((rng.uniform(0, 1, size=(n, Sc)) ** 5).astype(np.float32))
+        u = T(rng.uniform(0, 1, size=(n, Si)).astype(np.float32))
+        mid = 0.5 * (z[..., 1:] + z[..., :-1])
+        smp, inds = O.inverse_cdf(mid, w[..., 1:-1], u, return_inds=True)
+        zs, _ = torch.sort(torch.cat([z, smp], -1), -1)
+        out = ops.sample_fine(z.to(device), w.to(device), u.to(device), rays.to(device), want_samples=True, want_inds=True)
+        exact(out["inds"], inds, f"inds {Sc}+{Si}")
+        exact(out["samples"], smp, f"samples {Sc}+{Si}")
+        exact(out["z"], zs, f"sorted z {Sc}+{Si}")
+        exact(out["pts"], rays[:, None, 0:3] + rays[:, None, 3:6] * zs[..., None], "pts")
+        close(out["z_std"], torch.std(smp, dim=-1, unbiased=False), 2e-6, 1e-7, "z_std")
+        # shared deterministic uniforms
+        ud = ops.cached_linspace(Si, device)
+        out = ops.sample_fine(z.to(device), w.to(device), ud, rays.to(device))
+        smp = O.inverse_cdf(mid, w[..., 1:-1], O.det_uniforms(n, Si))
+        exact(out["z"], torch.sort(torch.cat([z, smp], -1), -1)[0], "det z")
+
+
+def test_mlp_forward(device):
+    g = golden("mlp")
+    qf = _query_fn()
+    m = _model(O.random_state_dict(21), device)
+    pts, vd = T(g["vd_pts"]).to(device), T(g["vd_viewdirs"]).to(device)
+    with torch.no_grad():
+        raw = qf(pts, vd, m)
+    assert raw.shape == (24, 8, 4)
+    close(raw, g["vd_raw"], 2e-5, 2e-5, "mlp raw vs reference")
+    # no view branch
+    sd = O.random_state_dict(22, use_viewdirs=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("views_linears")}
+    from nerf_amd.run_nerf_helpers import NeRF
+    m2 = NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+    m2.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        raw2 = qf(T(g["novd_pts"]).to(device), None, m2.to(device))
+    close(raw2, g["novd_raw"], 2e-5, 2e-5, "mlp raw (no view branch) vs reference")
+
+
+def test_mlp_forward_ragged_sizes_and_peaky_weights(device):
+    """Point counts that are not multiples of the 128-point tile, against the oracle on this host."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    qf = _query_fn()
+    sd = _peaky(O.random_state_dict(33), 30.0)
+    m = _model(sd, device)
+    for n, s in ((1, 1), (5, 7), (129, 3), (64, 64), (100, 192)):
+        pts = T(rng.uniform(-5, 5, size=(n, s, 3)).astype(np.float32))
+        vd = T(rng.normal(size=(n, 3)).astype(np.float32))
+        vd = vd / vd.norm(dim=-1, keepdim=True)
+        with torch.no_grad():
+            raw = qf(pts.to(device), vd.to(device), m)
+            want = O.query_field(pts, vd, sd)
+        scale = float(want.abs().max())
+        close(raw, want, 3e-5, 3e-6 * max(1.0, scale), f"mlp {n}x{s}")
+
+
+def _rng_inputs(n, sc, si, perturb, std):
+    np.random.seed(0)
+    t_rand = torch.Tensor(np.random.rand(n, sc)) if perturb > 0 else None
+    np.random.seed(0)
+    u = torch.Tensor(np.random.rand(n, si)) if (perturb > 0 and si > 0) else None
+    nc = nf = None
+    if std > 0:
+        np.random.seed(0)
+        nc = torch.Tensor(np.random.rand(n, sc) * std)
+        np.random.seed(0)
+        nf = torch.Tensor(np.random.rand(n, sc + si) * std)
+    return t_rand, u, nc, nf
+
+
+def test_render_matches_reference_outputs(device):
+    """render() through the public API on the configurations of the benchmark, against the reference's own outputs."""
+    from nerf_amd.run_nerf import render
+    g = golden("march")
+    mc = _model(_peaky(O.random_state_dict(31), 40.0), device)
+    mf = _model(_peaky(O.random_state_dict(32), 60.0), device)
+    qf = _query_fn()
+    for tag in ("lego_train", "lego_test", "fern_train", "lindisp", "coarse_only", "stress"):
+        sc, si, perturb, std, white, lindisp, near, far, ndc, H, W, focal = g[tag + ".cfg"]
+        sc, si, H, W = int(sc), int(si), int(H), int(W)
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        rays = T(g[tag + ".rays"]).to(device)
+        kw = dict(network_fn=mc, network_query_fn=qf, N_samples=sc, N_importance=si, network_fine=mf, perturb=perturb,
+                  raw_noise_std=std, white_bkgd=bool(white), lindisp=bool(lindisp), retraw=True, use_viewdirs=True,
+                  ndc=bool(ndc), near=near, far=far, pytest=(perturb > 0 or std > 0))
+        with torch.no_grad():
+            rgb, disp, acc, extras = render(H, W, K, chunk=1 << 15, rays=rays, **kw)
+        got = dict(extras, rgb_map=rgb, disp_map=disp, acc_map=acc)
+        for k in [k[len(tag) + 1:] for k in g if k.startswith(tag + ".") and k.split(".")[1] not in ("rays", "packed", "cfg")]:
+            want = g[f"{tag}.{k}"]
+            if k.startswith("disp"):
+                close(got[k], want, 1e-3, 1e-5, f"{tag} {k}")
+            elif k == "raw":
+                # the fine samples move by ~1e-6 with the coarse weights; raw follows with the network's slope
+                close(got[k], want, 1e-3, 2e-3, f"{tag} {k}")
+            else:
+                close(got[k], want, 2e-4, 2e-5, f"{tag} {k}")
+
+
+def test_render_whole_image_and_chunk_independence(device):
+    from nerf_amd.run_nerf import render
+    g = golden("image")
+    mc = _model(_peaky(O.random_state_dict(31), 40.0), device)
+    mf = _model(_peaky(O.random_state_dict(32), 60.0), device)
+    H, W, f = g["hwf"]
+    H, W = int(H), int(W)
+    K = np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]])
+    kw = dict(network_fn=mc, network_query_fn=_query_fn(), N_samples=64, N_importance=128, network_fine=mf, perturb=0.0,
+              white_bkgd=True, use_viewdirs=True, ndc=False, near=2.0, far=6.0)
+    with torch.no_grad():
+        rgb, disp, acc, extras = render(H, W, K, chunk=50, c2w=T(g["pose"]).to(device), **kw)
+        rgb2, disp2, acc2, _ = render(H, W, K, chunk=1 << 15, c2w=T(g["pose"]).to(device), **kw)
+    assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and extras["z_std"].shape == (H, W)
+    close(rgb, g["rgb"], 2e-4, 2e-5, "image rgb")
+    close(acc, g["acc"], 2e-4, 2e-5, "image acc")
+    close(disp, g["disp"], 1e-3, 1e-5, "image disp")
+    close(extras["z_std"], g["z_std"], 1e-3, 1e-5, "image z_std")
+    exact(rgb, rgb2, "chunk size must not change a deterministic render")
+    exact(disp, disp2, "chunk size (disp)")

@@ -1,0 +1,154 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, argument errors are
+reported without a GPU, the packed-weight layout covers every parameter, flags parse like upstream."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from nerf_amd._lib import lib
+    return lib
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(nerf_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 20
+    lib = ctypes.CDLL(os.path.join(ROOT, "nerf_amd", "libnerf_hip.so"))
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in nerf_hip.h but not exported: {missing}"
+    from nerf_amd._lib import SIGNATURES
+    assert names == set(SIGNATURES), names ^ set(SIGNATURES)
+
+
+def test_probes_and_argument_errors_need_no_gpu():
+    lib = _lib()
+    assert lib.nerf_version() == 1
+    assert lib.nerf_arch() == b"gfx950"
+    # argument validation happens before any launch
+    assert lib.nerf_get_rays(0, 10, 1.0, 1.0, 0.0, 0.0, None, None, None, None) == -1
+    assert b"nerf_get_rays" in lib.nerf_last_error()
+    assert lib.nerf_sample_fine(4, 2, 8, None, None, None, 0, None, 0, None, None, None, None, None, None) == -1
+    assert lib.nerf_composite_fwd(4, 0, None, None, None, 3, None, 0, None, None, None, None, None, None) == -1
+    assert lib.nerf_mlp_fwd(8, 1, None, None, 1, 4, None, None, None, None) == -1
+    assert b"null pointer" in lib.nerf_last_error()
+    # empty inputs are a successful no-op
+    assert lib.nerf_ndc_rays(0, 1.0, 1.0, 1.0, None, None, None, None, None) == 0
+    assert lib.nerf_mlp_fwd(0, 1, None, None, 1, 4, None, None, None, None) == 0
+
+
+@pytest.mark.parametrize("use_viewdirs,output_ch", [(1, 5), (0, 5), (0, 4)])
+def test_packed_streams_cover_every_weight_once(use_viewdirs, output_ch):
+    lib = _lib()
+    from oracle import nerf_oracle as O
+    n_params = lib.nerf_mlp_n_params(use_viewdirs, output_ch)
+    in_dirs = 27 if use_viewdirs else 0
+    shapes = O.layer_shapes(use_viewdirs=bool(use_viewdirs), output_ch=output_ch, in_dirs=in_dirs)
+    # flat layout = state_dict order of the module
+    from nerf_amd.run_nerf_helpers import NeRF
+    m = NeRF(D=8, W=256, input_ch=63, input_ch_views=in_dirs, output_ch=output_ch, skips=[4], use_viewdirs=bool(use_viewdirs))
+    assert sum(p.numel() for p in m.parameters()) == n_params == sum(o * i + o for _, o, i in shapes)
+    offsets, off = {}, 0
+    for name, p in m.named_parameters():
+        offsets[name] = (off, p.numel())
+        off += p.numel()
+
+    nf = lib.nerf_mlp_packed_floats(use_viewdirs)
+    table = np.empty(nf, dtype=np.int64)
+    assert lib.nerf_pack_source_table(use_viewdirs, output_ch, 0, table.ctypes.data, nf) == 0
+    used = table[table >= 0]
+    counts = np.bincount(used, minlength=n_params)
+    dead = np.zeros(n_params, dtype=bool)
+    if not use_viewdirs:  # views_linears.0 exists in the state_dict but the forward never reads it
+        a, n = offsets["views_linears.0.weight"]
+        dead[a:a + n] = True
+        a, n = offsets["views_linears.0.bias"]
+        dead[a:a + n] = True
+    assert (counts[~dead] == 1).all(), "every live parameter appears exactly once in the forward stream"
+    assert (counts[dead] == 0).all()
+    assert nf % 4 == 0 and (nf * 4) % 16 == 0
+
+    nb = lib.nerf_mlp_packed_bwd_floats(use_viewdirs)
+    tb = np.empty(nb, dtype=np.int64)
+    assert lib.nerf_pack_source_table(use_viewdirs, output_ch, 1, tb.ctypes.data, nb) == 0
+    assert (tb >= 0).all()
+    cb = np.bincount(tb, minlength=n_params)
+    # the transposed stream holds the hidden-to-hidden weights (layers 1..7 without the skip columns) and,
+    # with view directions, feature_linear and the feature columns of views_linears.0
+    expect = np.zeros(n_params, dtype=np.int64)
+    for i in range(1, 8):
+        a, n = offsets[f"pts_linears.{i}.weight"]
+        w = np.ones((256, n // 256), dtype=np.int64)
+        if i == 5:
+            w[:, :63] = 0
+        expect[a:a + n] = w.reshape(-1)
+    if use_viewdirs:
+        a, n = offsets["feature_linear.weight"]
+        expect[a:a + n] = 1
+        a, n = offsets["views_linears.0.weight"]
+        w = np.zeros((128, 283), dtype=np.int64)
+        w[:, :256] = 1
+        expect[a:a + n] = w.reshape(-1)
+    assert np.array_equal(cb, expect)
+
+
+def test_state_dict_layout_matches_upstream_checkpoint_contract():
+    from nerf_amd.run_nerf_helpers import NeRF
+    m = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    sd = m.state_dict()
+    assert list(sd)[:4] == ["pts_linears.0.weight", "pts_linears.0.bias", "pts_linears.1.weight", "pts_linears.1.bias"]
+    assert sd["pts_linears.5.weight"].shape == (256, 319)
+    assert sd["views_linears.0.weight"].shape == (128, 283)
+    assert sd["alpha_linear.weight"].shape == (1, 256) and sd["rgb_linear.weight"].shape == (3, 128)
+    assert sum(v.numel() for v in sd.values()) == 595844
+    from oracle import nerf_oracle as O
+    assert set(O.random_state_dict(0)) == set(sd)
+    m.load_state_dict(O.random_state_dict(0))
+
+
+def test_unsupported_architecture_fails_loudly():
+    from nerf_amd.run_nerf_helpers import NeRF, Embedder
+    m = NeRF(D=4, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    with pytest.raises(NotImplementedError):
+        m._check_arch()
+    with pytest.raises(NotImplementedError):
+        Embedder(include_input=False, input_dims=3, max_freq_log2=9, num_freqs=10, log_sampling=True,
+                 periodic_fns=[torch.sin, torch.cos])
+
+
+def test_config_parser_reads_upstream_style_config(tmp_path):
+    from nerf_amd.run_nerf import config_parser
+    cfg = tmp_path / "lego.txt"
+    cfg.write_text("expname = blender_paper_lego\nbasedir = ./logs\ndataset_type = blender\n\nno_batching = True\n"
+                   "use_viewdirs = True\nwhite_bkgd = True\nlrate_decay = 500\n\nN_samples = 64\nN_importance = 128\n"
+                   "N_rand = 1024\n\nprecrop_iters = 500\nprecrop_frac = 0.5\n\nhalf_res = True\n")
+    args = config_parser().parse_args(["--config", str(cfg), "--N_rand", "2048"])
+    assert args.expname == "blender_paper_lego" and args.dataset_type == "blender"
+    assert args.no_batching and args.use_viewdirs and args.white_bkgd and args.half_res
+    assert args.N_samples == 64 and args.N_importance == 128 and args.lrate_decay == 500
+    assert args.N_rand == 2048  # the command line wins over the file
+    assert args.chunk == 1024 * 32 and args.netchunk == 1024 * 64 and args.perturb == 1.0 and args.lrate == 5e-4
+    assert args.multires == 10 and args.multires_views == 4 and args.i_embed == 0 and not args.render_only
+    fern = tmp_path / "fern.txt"
+    fern.write_text("expname = fern_test\nfactor = 8\nN_samples = 64 # Coarse sampling\nN_importance = 64\n"
+                    "use_viewdirs = True\nraw_noise_std = 1e0\n")
+    a2 = config_parser().parse_args(["--config", str(fern)])
+    assert a2.raw_noise_std == 1.0 and a2.N_importance == 64 and a2.dataset_type == "llff" and not a2.no_ndc
+
+
+def test_product_path_has_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nerf_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.device()
+    from nerf_amd.run_nerf_helpers import get_rays
+    with pytest.raises(RuntimeError):
+        get_rays(4, 4, np.array([[4., 0, 2], [0, 4., 2], [0, 0, 1]]), torch.eye(4)[:3])
