@@ -1,0 +1,176 @@
+"""Benchmark of the render path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one batch of synthetic input: a no-grad render of one full
+800x800 lego-shaped view (640,000 rays, 64 coarse + 128 fine samples, white background, view
+directions, chunk 32768) through the public render() entry point — BASELINE.json configs[1].
+Inputs (poses, weights) are resident in HBM before the timed region.  With N > 1 every rank renders
+its own view of the orbit (rays are independent: no data-path collective), value = all rays / max
+time over ranks.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline:     the fused encode+MLP kernel (the dominant kernel), algorithmic FLOP per launch /
+                mean launch duration measured with HIP events on the launch stream, against the
+                fp32 matrix peak of MI355X;
+  cpu_baseline: the CPU oracle (a PyTorch-CPU restatement of the reference path, proven equal to
+                the reference on the golden fixtures) timed on this host on a bounded ray sample;
+  train:        (when the backward is available) one lego train step, rays/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT_FWD = 1186816          # 2 * 593,408 MAC: one NeRF.forward on one sample point
+FLOP_PER_POINT_TRAIN = 3489024        # forward + dW + dX
+PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X v_mfma_f32_32x32x2_f32 peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
+
+
+def lego_camera(H, W):
+    focal = .5 * W / np.tan(.5 * 0.6911112070083618)
+    return np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+
+
+def build_scene(dev, seed=0):
+    from nerf_amd.run_nerf import run_network
+    from nerf_amd.run_nerf_helpers import NeRF, get_embedder
+    from oracle import nerf_oracle as O
+    sds = []
+    models = []
+    for s in (seed, seed + 1):
+        sd = O.random_state_dict(s)
+        sd["alpha_linear.weight"] *= 30.0          # random init is almost transparent; give the rays something to hit
+        sd["alpha_linear.bias"] += 0.3
+        m = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        m.load_state_dict(sd)
+        models.append(m.to(dev))
+        sds.append(sd)
+    e, _ = get_embedder(10, 0)
+    ed, _ = get_embedder(4, 0)
+    qf = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=e, embeddirs_fn=ed, netchunk=1024 * 64)
+    kwargs = dict(network_query_fn=qf, perturb=0., N_importance=128, network_fine=models[1], N_samples=64,
+                  network_fn=models[0], use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False,
+                  near=2., far=6.)
+    return models, sds, kwargs
+
+
+def cpu_baseline(sds, pose, H, W, K, n_rays):
+    """The oracle on `n_rays` rays of the benchmark view, all host threads PyTorch was given."""
+    from oracle import nerf_oracle as O
+    with torch.no_grad():
+        o, d = O.pixel_rays(H, W, K, pose)
+        rng = np.random.Generator(np.random.PCG64(0))
+        pick = torch.from_numpy(rng.choice(H * W, size=n_rays, replace=False))
+        rays = O.pack_rays(o.reshape(-1, 3)[pick], d.reshape(-1, 3)[pick], 2., 6., use_viewdirs=True)
+        kw = dict(sd_coarse=sds[0], sd_fine=sds[1], n_coarse=64, n_fine=128, white_bkgd=True)
+        O.render_chunks(rays[:256], 1 << 15, **kw)  # warm-up
+        t0 = time.perf_counter()
+        out = O.render_chunks(rays, 1 << 15, **kw)
+        dt = time.perf_counter() - t0
+    return n_rays / dt, out, pick
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=800, help="image side; 800 is the benchmark configuration")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--no-train", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nerf_amd import ops
+    from nerf_amd.run_nerf import render
+    from oracle import nerf_oracle as O
+
+    H = W = args.res
+    K = lego_camera(H, W)
+    models, sds, kwargs = build_scene(dev)
+    thetas = np.linspace(-180, 180, 40 + 1)[:-1]
+    n_views = args.warmup + args.steps
+    poses = [O.orbit_pose(float(thetas[(rank * n_views + i) % 40]), -30.0, 4.0)[:3, :4].to(dev) for i in range(n_views)]
+    chunk = 1024 * 32
+
+    def step(i):
+        with torch.no_grad():
+            return render(H, W, K, chunk=chunk, c2w=poses[i], **kwargs)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    ops.PROFILE = []
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rays_per_step = H * W
+    value = rays_per_step * args.steps * world / dt
+
+    # dominant kernel: fused encode + MLP forward, timed per launch with events on the launch stream
+    mlp = [(n, s.elapsed_time(e) * 1e-3) for (name, n, s, e) in prof if name == "mlp_fwd"]
+    pts = sum(n for n, _ in mlp)
+    secs = sum(t for _, t in mlp)
+    achieved = pts * FLOP_PER_POINT_FWD / secs / 1e12 if secs > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd<viewdirs, inference> (fp32 MFMA 32x32x2)", "achieved": round(achieved, 2),
+                "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "traffic": None, "launches": len(mlp), "mean_launch_ms": round(1e3 * secs / max(1, len(mlp)), 3),
+                "flop_per_point": FLOP_PER_POINT_FWD, "mlp_share_of_step": round(secs / dt, 4)}
+
+    out = {"metric": "rays/sec per GPU (train step + render) at 64+128 samples; 1/2/4/8 GPU scaling",
+           "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"lego {H}x{W} render_only, N_samples=64, N_importance=128, chunk={chunk}, white_bkgd, "
+                                  "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
+                      "parallelism": f"ray/view-sharded x{world}, no collective"},
+           "roofline": roofline}
+
+    if rank == 0:
+        if args.cpu_rays > 0:
+            cpu_rps, cpu_out, pick = cpu_baseline(sds, poses[-1].cpu(), H, W, K, args.cpu_rays)
+            got = last[0].reshape(-1, 3)[pick.to(dev)].cpu()
+            err = float((got - cpu_out["rgb_map"]).abs().max())
+            out["cpu_baseline"] = {"value": round(cpu_rps, 1), "unit": "rays/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": f"{args.cpu_rays} random rays of the last benchmark view, "
+                                   "same weights, PyTorch-CPU oracle", "host_cpus": os.cpu_count(),
+                                   "max_abs_rgb_diff_vs_gpu": err, "speedup_per_gpu": round(value / world / cpu_rps, 1)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,10 @@ import torch
 from ._lib import check, lib
 
 
+# When set to a list, kernel launches append (name, units, start_event, end_event) recorded on the launch stream.
+PROFILE = None
+
+
 def device() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError("nerf_amd needs a HIP device: torch.cuda.is_available() is False and there is no CPU path")
@@ -242,8 +246,14 @@ def mlp_forward(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_fwd:
         viewdirs = _f32c(viewdirs, "viewdirs")
         assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
     with torch.cuda.device(pts.device):
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         check(lib.nerf_mlp_fwd(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
                                int(use_viewdirs), output_ch, packed_fwd.data_ptr(), out.data_ptr(), _ptr(act), _stream()))
+        if PROFILE is not None:
+            ev1.record()
+            PROFILE.append(("mlp_fwd", n_pts, ev0, ev1))
     return out
 
 
