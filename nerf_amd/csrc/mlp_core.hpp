@@ -1,0 +1,99 @@
+// Device-side machinery shared by the fused MLP kernels: the LDS slab ring that streams packed
+// weight blocks, and the section loop that turns blocks into chains of v_mfma_f32_32x32x2_f32 on
+// register-resident activation tiles (layout: mlp_layout.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <utility>
+#include "mlp_layout.hpp"
+
+namespace nerfmlp {
+using namespace nerflayout;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int RING_FLOATS = 2 * SLAB_FLOATS;
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// The weight stream as seen by one wave: a double-buffered slab ring in LDS.
+struct Stream {
+    const float* g;   // this lane's source pointer for block 4*wave of slab 0
+    float* ring;      // LDS ring base
+    float* mine;      // this wave's destination inside a slab (wave-uniform)
+    int next;         // next slab to consume
+    int nslabs;
+
+    __device__ __forceinline__ void fetch(int slab) {
+        const float* src = g + (int64_t)slab * SLAB_FLOATS;
+        float* dst = mine + (slab & 1) * SLAB_FLOATS;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
+    }
+    // Make slab `next` readable, start fetching the one after it, return this lane's read pointer.
+    __device__ __forceinline__ const float* advance(int lane) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's quarter of slab `next` has landed; all reads of the other buffer are done
+        const float* cur = ring + (next & 1) * SLAB_FLOATS + lane * 4;
+        if (next + 1 < nslabs) fetch(next + 1);
+        ++next;
+        return cur;
+    }
+};
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// compile-time loop: body.template operator()<i>() for i = 0..N-1.  Register tiles are indexed by
+// these constants only; a run-time index would send the whole tile array to scratch memory.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f.template operator()<I>(), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// acc[to] (+)= sum over NIN input tiles: one section of NOUT*NIN*4 blocks = NOUT*NIN/4 slabs.
+// The LDS reads run DEPTH blocks ahead of the MFMAs that consume them, also across the slab barrier:
+// the last MFMAs of a slab issue after the barrier and behind the first reads of the next slab, so
+// neither the LDS latency nor the barrier leaves the matrix pipe idle.
+template <int NOUT, int NIN, bool ACCUM, typename InTile>
+__device__ __forceinline__ void run_section(Stream& st, int lane, f32x16 (&acc)[8], InTile in_tile) {
+    constexpr int NB = NOUT * NIN * 4, DEPTH = 2;
+    static_assert(NB % SLAB_BLOCKS == 0, "sections are whole slabs");
+    f32x4 abuf[DEPTH + 1];
+    const float* cur = nullptr;
+    static_for<NB + DEPTH>([&]<int I>() {
+        if constexpr (I < NB) {
+            if constexpr (I % SLAB_BLOCKS == 0) cur = st.advance(lane);
+            abuf[I % (DEPTH + 1)] = *reinterpret_cast<const f32x4*>(cur + (I % SLAB_BLOCKS) * BLOCK_FLOATS);
+        }
+        if constexpr (I >= DEPTH) {
+            constexpr int b = I - DEPTH;
+            constexpr int to = b / (NIN * 4), ti = (b >> 2) % NIN, q = b & 3;
+            const f32x4 a = abuf[b % (DEPTH + 1)];
+            if constexpr (!ACCUM && ti == 0 && q == 0) {
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc[to] = mfma(a[0], in_tile.template operator()<ti>()[0], zero);
+            } else {
+                acc[to] = mfma(a[0], in_tile.template operator()<ti>()[4 * q + 0], acc[to]);
+            }
+            acc[to] = mfma(a[1], in_tile.template operator()<ti>()[4 * q + 1], acc[to]);
+            acc[to] = mfma(a[2], in_tile.template operator()<ti>()[4 * q + 2], acc[to]);
+            acc[to] = mfma(a[3], in_tile.template operator()<ti>()[4 * q + 3], acc[to]);
+        }
+        // keep the read of block I ahead of the MFMAs of block I-DEPTH+1: the scheduler would otherwise sink
+        // every read to just before its first use and expose the LDS latency once per block pair
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+
+}  // namespace nerfmlp

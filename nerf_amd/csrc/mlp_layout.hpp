@@ -227,4 +227,22 @@ NL_HD inline int64_t act_floats(int use_viewdirs, int64_t n_pts) {
     return (int64_t)(use_viewdirs ? ACT_ROWS : ACT_FEAT) * padded_points(n_pts);
 }
 
+// ---- backward workspace --------------------------------------------------------------------------
+// Rows of `ldp` floats holding dL/d(pre-activation) of every layer, in the layout of the activations:
+//   rows 0..2047 pts layers 0..7 | 2048..2303 feature_linear | 2304..2431 views layer |
+//   2432..2463 head rows A: dL/d(rgb) (view branch) or dL/d(out channel c), the rest zero
+//   2464..2495 head rows B: dL/d(sigma) in the first row (view branch), the rest zero.
+// Then KSPLIT slabs of partial parameter gradients (one per slice of the point range), each
+// `slab_floats` long, summed in slab order by the final reduction.
+constexpr int SCR_H0 = 0, SCR_FEAT = 8 * 256, SCR_VIEWS = SCR_FEAT + 256, SCR_HEAD = SCR_VIEWS + 128;
+constexpr int SCR_HEAD2 = SCR_HEAD + 32;
+constexpr int SCR_ROWS = SCR_HEAD2 + 32;
+constexpr int KSPLIT = 32;
+NL_HD inline int64_t slab_floats(int use_viewdirs, int output_ch) {
+    return (param_offsets(use_viewdirs, output_ch).total + 63) / 64 * 64;
+}
+NL_HD inline int64_t scratch_floats(int use_viewdirs, int output_ch, int64_t n_pts) {
+    return (int64_t)SCR_ROWS * padded_points(n_pts) + (int64_t)KSPLIT * slab_floats(use_viewdirs, output_ch);
+}
+
 }  // namespace nerflayout

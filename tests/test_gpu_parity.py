@@ -344,3 +344,109 @@ def test_render_whole_image_and_chunk_independence(device):
     close(extras["z_std"], g["z_std"], 1e-3, 1e-5, "image z_std")
     exact(rgb, rgb2, "chunk size must not change a deterministic render")
     exact(disp, disp2, "chunk size (disp)")
+
+
+# ---------------------------------------------------------------------------------------------
+# gradients
+# ---------------------------------------------------------------------------------------------
+def _grad_close(got, want, what, rtol=2e-3, atol_frac=2e-5):
+    """Gradients are sums over points of products of O(1) terms: compare against the tensor's own scale."""
+    got = got.detach().cpu().numpy()
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    scale = max(float(np.abs(want).max()), 1e-12)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_frac * scale, err_msg=what)
+
+
+def test_mlp_backward_matches_reference_and_oracle(device):
+    g = golden("mlp")
+    qf = _query_fn()
+    sd = O.random_state_dict(21)
+    m = _model(sd, device)
+    pts, vd, G = T(g["vd_pts"]), T(g["vd_viewdirs"]), T(g["vd_G"])
+    raw = qf(pts.to(device), vd.to(device), m)
+    (raw * G.to(device)).sum().backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (O.query_field(pts, vd, params) * G).sum().backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        _grad_close(p.grad, params[k].grad, "grad vs oracle " + k)
+        flat = p.grad.reshape(-1)
+        ref = g[f"vd_gsample.{k}"]
+        scale = max(float(np.abs(params[k].grad.numpy()).max()), 1e-12)
+        np.testing.assert_allclose(flat[:: max(1, flat.numel() // 64)][:64].cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * scale,
+                                   err_msg="grad vs reference " + k)
+        sums = np.array([flat.double().sum().item(), flat.double().abs().sum().item()])
+        np.testing.assert_allclose(sums[1], g[f"vd_gsum.{k}"][1], rtol=1e-4)
+
+
+def test_mlp_backward_sizes_and_no_view_branch(device):
+    """Ragged point counts (tile padding, empty K slices) and the output_linear head, against oracle autograd."""
+    rng = np.random.Generator(np.random.PCG64(10))
+    qf = _query_fn()
+    for use_vd, n, s in ((True, 3, 5), (True, 70, 64), (False, 33, 8), (True, 300, 192)):
+        if use_vd:
+            sd = _peaky(O.random_state_dict(50 + n), 5.0)
+            m = _model(sd, device)
+        else:
+            sd = O.random_state_dict(60, use_viewdirs=False)
+            sd = {k: v for k, v in sd.items() if not k.startswith("views_linears")}
+            from nerf_amd.run_nerf_helpers import NeRF
+            m = NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+            m.load_state_dict(sd, strict=False)
+            m = m.to(device)
+        pts = T(rng.uniform(-3, 3, size=(n, s, 3)).astype(np.float32))
+        vd = T(rng.normal(size=(n, 3)).astype(np.float32))
+        vd = vd / vd.norm(dim=-1, keepdim=True)
+        raw = qf(pts.to(device), vd.to(device) if use_vd else None, m)
+        G = T(rng.normal(size=tuple(raw.shape)).astype(np.float32))
+        (raw * G.to(device)).sum().backward()
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        (O.query_field(pts, vd if use_vd else None, params) * G).sum().backward()
+        for k, p in m.named_parameters():
+            if k.startswith("views_linears") and not use_vd:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0
+                continue
+            _grad_close(p.grad, params[k].grad, f"grad {k} ({n}x{s}, viewdirs={use_vd})")
+
+
+def test_train_step_matches_reference(device):
+    """One lego-shaped optimisation step through the public API: loss, every gradient, post-Adam weights."""
+    from nerf_amd.run_nerf import render
+    from nerf_amd.run_nerf_helpers import img2mse, mse2psnr
+    g = golden("train_step")
+    mc = _model(_peaky(O.random_state_dict(41), 20.0), device)
+    mf = _model(_peaky(O.random_state_dict(42), 20.0), device)
+    rays, target = T(g["rays"]).to(device), T(g["target"]).to(device)
+    H = W = 400
+    focal = 555.5555155968841
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    params = list(mc.parameters()) + list(mf.parameters())
+    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
+    kw = dict(network_fn=mc, network_query_fn=_query_fn(), N_samples=64, N_importance=128, network_fine=mf, perturb=1.0,
+              raw_noise_std=0.0, white_bkgd=True, use_viewdirs=True, ndc=False, near=2.0, far=6.0, pytest=True, retraw=True)
+    rgb, disp, acc, extras = render(H, W, K, chunk=1 << 15, rays=rays, verbose=True, **kw)
+    opt.zero_grad()
+    img_loss = img2mse(rgb, target)
+    loss = img_loss + img2mse(extras["rgb0"], target)
+    close(loss, g["loss"], 1e-5, 0, "loss")
+    close(mse2psnr(img_loss), g["psnr"], 1e-5, 0, "psnr")
+    loss.backward()
+    names = [("c." + k) for k, _ in mc.named_parameters()] + [("f." + k) for k, _ in mf.named_parameters()]
+    for k, p in zip(names, params):
+        flat = p.grad.reshape(-1)
+        want = g["gsample." + k]
+        scale = g["gsum." + k][1] / flat.numel()  # mean |grad| of the whole tensor
+        np.testing.assert_allclose(flat[:: max(1, flat.numel() // 64)][:64].cpu().numpy(), want, rtol=5e-3,
+                                   atol=2e-3 * scale, err_msg="grad " + k)
+        np.testing.assert_allclose(flat.double().abs().sum().item(), g["gsum." + k][1], rtol=1e-3, err_msg="|grad| " + k)
+    opt.step()
+    for k, p in zip(names, params):
+        flat = p.detach().reshape(-1)
+        # Adam's first step moves every weight by lr * sign(g) (up to eps): equality of the updated weights
+        # is equality of the gradient signs wherever |g| is not ~0
+        np.testing.assert_allclose(flat[:: max(1, flat.numel() // 64)][:64].cpu().numpy(), g["wsample." + k], rtol=0,
+                                   atol=1.1e-3, err_msg="weight " + k)
+    # the repacked streams must follow the optimiser step
+    with torch.no_grad():
+        rgb2, _, _, _ = render(H, W, K, chunk=1 << 15, rays=rays, **dict(kw, retraw=False))
+    assert float((rgb2 - rgb).abs().max()) > 0.0
