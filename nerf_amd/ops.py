@@ -278,7 +278,7 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, viewdirs, model, pts_per_ray, *params):
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad[4:])  # grad mode is off inside forward(); autograd tells us here
         fwd, bwd, flat = model._packed(need_grad)
         n_pts = pts.numel() // 3
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
