@@ -78,6 +78,70 @@ def cpu_baseline(sds, pose, H, W, K, n_rays):
     return n_rays / dt, out, pick
 
 
+def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
+    """The upstream optimisation step (run_nerf.py:826-883, no_batching mode) on synthetic targets: rays of one
+    400x400 view, n_rand random pixels, render with jitter, two MSE terms, backward, (all-reduce,) Adam, lr decay."""
+    from nerf_amd import ops, parallel
+    from nerf_amd.run_nerf import render
+    from nerf_amd.run_nerf_helpers import get_rays, img2mse
+    from oracle import nerf_oracle as O
+    H = W = 400
+    K = lego_camera(H, W)
+    kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
+    params = list(models[0].parameters()) + list(models[1].parameters())
+    saved = [p.detach().clone() for p in params]
+    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    thetas = np.linspace(-180, 180, 41)[:-1]
+    poses = [O.orbit_pose(float(thetas[i % 40]), -30.0, 4.0)[:3, :4].to(dev) for i in range(warmup + steps)]
+    target_img = torch.rand(H * W, 3, device=dev, generator=gen)
+
+    def one(i):
+        rays_o, rays_d = get_rays(H, W, K, poses[i])
+        sel = torch.randperm(H * W, device=dev, generator=gen)[:n_rand]
+        batch_rays = torch.stack([rays_o.reshape(-1, 3)[sel], rays_d.reshape(-1, 3)[sel]], 0)
+        target = target_img[sel]
+        rgb, disp, acc, extras = render(H, W, K, chunk=1024 * 32, rays=batch_rays, verbose=False, retraw=True, **kw)
+        opt.zero_grad()
+        loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_gradients(params)
+        opt.step()
+        for g in opt.param_groups:
+            g['lr'] = 5e-4 * (0.1 ** (i / (500 * 1000)))
+        return loss
+
+    for i in range(warmup):
+        one(i)
+    ops.PROFILE = []
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one(warmup + i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    with torch.no_grad():
+        for p, s0 in zip(params, saved):
+            p.copy_(s0)
+    kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in ("mlp_fwd", "mlp_bwd"))
+    flop = n_rand * 256 * FLOP_PER_POINT_TRAIN * steps
+    return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "n_rand_per_gpu": n_rand,
+            "steps": steps, "final_loss": float(loss), "mlp_kernels_share_of_step": round(kern / dt, 4),
+            "mlp_tflops_algorithmic": round(flop / kern / 1e12, 2) if kern > 0 else None,
+            "frac_of_fp32_matrix_peak": round(flop / kern / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if kern > 0 else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +221,11 @@ def main():
                                   "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
                       "parallelism": f"ray/view-sharded x{world}, no collective"},
            "roofline": roofline}
+
+    if not args.no_train:
+        # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)
+        out["train"] = time_train(models, kwargs, dev, world, 1024, 10, 3, seed=1234 + rank)
+        out["train_8192"] = time_train(models, kwargs, dev, world, 8192, 4, 2, seed=4321 + rank)
 
     if rank == 0:
         if args.cpu_rays > 0:

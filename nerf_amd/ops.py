@@ -268,8 +268,14 @@ def mlp_backward(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, pac
     scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
     d_flat = torch.empty_like(flat)
     with torch.cuda.device(d_out.device):
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         check(lib.nerf_mlp_bwd(n_pts, pts_per_ray, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
                                packed_fwd.data_ptr(), packed_bwd.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(), _stream()))
+        if PROFILE is not None:
+            ev1.record()
+            PROFILE.append(("mlp_bwd", n_pts, ev0, ev1))
     return d_flat
 
 

@@ -1,0 +1,111 @@
+"""Multi-GPU use of the render path: one process per GPU, torch.distributed over RCCL (backend "nccl").
+
+The upstream program is single-process; rays are independent, so the two extensions are
+  * render_sharded: the flat ray list of one view is cut into world_size contiguous slices, every
+    rank runs the unchanged single-GPU path on its slice, and ONE all_gather of rgb/disp/acc
+    (20 bytes per ray) reassembles the image on every rank;
+  * allreduce_gradients: data-parallel training.  Each rank draws its own rays, then the gradients
+    of both networks travel as ONE flat fp32 bucket (2 x 595,844 floats = 4.77 MB) through a single
+    all_reduce(SUM) and are scaled by 1/world_size.  Because the loss is a mean over equally sized
+    shards, the result equals the gradient of the world_size-times larger batch.  At this size the
+    collective is latency-bound over xGMI; one bucket means one latency.
+Both work on any backend (the CPU tests use gloo).
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [begin, end) of `n` items for `rank`: the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Concatenate per-rank row blocks cut by shard_bounds (blocks differ by at most one row)."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    rows = (n_total + world - 1) // world
+    pad = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    parts = []
+    for r in range(world):
+        b, e = shard_bounds(n_total, r, world)
+        parts.append(out[r * rows: r * rows + (e - b)])
+    return torch.cat(parts, 0)
+
+
+def render_sharded(H: int, W: int, K, chunk: int, rays, render_fn: Optional[Callable] = None, group=None, **render_kwargs):
+    """Render `rays` = (rays_o [N,3], rays_d [N,3]) with the ray list split across ranks.
+
+    Returns (rgb [N,3], disp [N], acc [N]) complete on every rank.  render_fn defaults to
+    nerf_amd.run_nerf.render and is called as render_fn(H, W, K, chunk=chunk, rays=(o, d), **render_kwargs)."""
+    if render_fn is None:
+        from .run_nerf import render as render_fn
+    rank, world = _world(group)
+    rays_o, rays_d = rays
+    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    n = rays_o.shape[0]
+    b, e = shard_bounds(n, rank, world)
+    rgb, disp, acc, _ = render_fn(H, W, K, chunk=chunk, rays=(rays_o[b:e], rays_d[b:e]), **render_kwargs)
+    packed = torch.cat([rgb.reshape(-1, 3), disp.reshape(-1, 1), acc.reshape(-1, 1)], -1)  # one collective, 20 B/ray
+    full = all_gather_rows(packed.contiguous(), n, group)
+    return full[:, 0:3], full[:, 3], full[:, 4]
+
+
+def flatten_gradients(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """One contiguous fp32 bucket holding every gradient (zeros where a parameter has none)."""
+    chunks = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
+    return torch.cat(chunks)
+
+
+def unflatten_into_gradients(bucket: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
+    off = 0
+    for p in params:
+        g = bucket[off: off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+
+
+def allreduce_gradients(params: Iterable[torch.Tensor], group=None) -> None:
+    """Average the gradients of `params` over all ranks with a single all_reduce."""
+    params = [p for p in params if p.requires_grad]
+    rank, world = _world(group)
+    if world == 1 or not params:
+        return
+    bucket = flatten_gradients(params)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    bucket.mul_(1.0 / world)
+    unflatten_into_gradients(bucket, params)
+
+
+def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=None) -> None:
+    """Make every rank start from rank `src`'s weights (one flat broadcast)."""
+    params = list(params)
+    rank, world = _world(group)
+    if world == 1 or not params:
+        return
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for p in params:
+            p.copy_(flat[off: off + p.numel()].view_as(p))
+            off += p.numel()

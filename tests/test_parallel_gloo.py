@@ -1,0 +1,102 @@
+"""world_size-2 checks of the multi-GPU helpers on CPU (gloo): ray sharding + gather, gradient bucket all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def test_shard_bounds_cover_and_balance():
+    from nerf_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 8, 640000, 160001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_render(H, W, K, chunk, rays, **kw):
+    o, d = rays
+    rgb = o * 2.0 + d
+    disp = (o * d).sum(-1)
+    acc = d[:, 0] - o[:, 1]
+    return [rgb, disp, acc, {}]
+
+
+def _sharded(rank, world):
+    from nerf_amd.parallel import render_sharded
+    g = torch.Generator().manual_seed(3)
+    o, d = torch.randn(101, 3, generator=g), torch.randn(101, 3, generator=g)
+    rgb, disp, acc = render_sharded(4, 4, None, 16, (o, d), render_fn=_fake_render)
+    want = _fake_render(4, 4, None, 16, (o, d))
+    return bool(torch.equal(rgb, want[0]) and torch.equal(disp, want[1]) and torch.equal(acc, want[2]))
+
+
+def test_render_sharded_reassembles_image_on_every_rank():
+    assert _run(_sharded) == [True, True]
+    assert _run(_sharded, world=3) == [True, True, True]
+
+
+def _dp(rank, world):
+    from nerf_amd.parallel import allreduce_gradients, broadcast_parameters
+    torch.manual_seed(100 + rank)  # ranks start apart, as independently initialised processes would
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    frozen = torch.nn.Linear(2, 2)
+    for p in frozen.parameters():
+        p.requires_grad_(False)
+    params = list(net.parameters()) + list(frozen.parameters())
+    broadcast_parameters(params, src=0)
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(8 * world, 6, generator=g), torch.randn(8 * world, 3, generator=g)
+    xs, ys = x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8]
+    torch.mean((net(xs) - ys) ** 2).backward()
+    allreduce_gradients(params)
+    got = [p.grad.clone() for p in net.parameters()]
+    # the same weights on the full batch in one process
+    net.zero_grad()
+    torch.mean((net(x) - y) ** 2).backward()
+    ok = all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7) for a, p in zip(got, net.parameters()))
+    return ok, [float(p.detach().sum()) for p in net.parameters()]
+
+
+def test_gradient_bucket_allreduce_equals_full_batch_gradient():
+    res = _run(_dp)
+    assert all(ok for ok, _ in res)
+    assert res[0][1] == res[1][1], "broadcast_parameters must leave identical weights on every rank"
+
+
+def test_single_process_is_a_no_op():
+    from nerf_amd.parallel import allreduce_gradients, all_gather_rows
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    allreduce_gradients([p])
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
+    t = torch.arange(6.).reshape(3, 2)
+    assert all_gather_rows(t, 3) is t
