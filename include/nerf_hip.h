@@ -123,6 +123,13 @@ int nerf_pack_source_table(int use_viewdirs, int output_ch, int backward, int64_
 int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, float* packed_fwd,
                       float* packed_bwd, void* stream);
 
+/* The same packing as a gather through a precomputed map: nerf_pack_table fills `table` (DEVICE,
+ * int32, nerf_mlp_packed_floats + nerf_mlp_packed_bwd_floats entries) once per model shape;
+ * nerf_pack_weights_table then repacks in a few microseconds after every optimiser step. */
+int nerf_pack_table(int use_viewdirs, int output_ch, int32_t* table, void* stream);
+int nerf_pack_weights_table(int use_viewdirs, const int32_t* table, const float* params, float* packed_fwd,
+                            float* packed_bwd, void* stream);
+
 /* NeRF.forward on encoded points (run_nerf_helpers.py:109-133 after run_nerf.py:46-58).
  * pts [n_pts,3]; viewdirs [n_rays,3] (ray of point p = p / pts_per_ray) or NULL when the network
  * has no view branch; out [n_pts, out_ch] (out_ch = 4 with view directions, else output_ch).

@@ -43,6 +43,8 @@ SIGNATURES = {
     "nerf_pack_source": (_l, [_i, _i, _i, _l]),
     "nerf_pack_source_table": (_i, [_i, _i, _i, _p, _l]),
     "nerf_pack_weights": (_i, [_i, _i, _p, _p, _p, _p]),
+    "nerf_pack_table": (_i, [_i, _i, _p, _p]),
+    "nerf_pack_weights_table": (_i, [_i, _p, _p, _p, _p, _p]),
     "nerf_mlp_fwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_mlp_bwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
 }

@@ -154,6 +154,7 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
 // stage 2
 // ------------------------------------------------------------------------------------------------
 struct DwTask {
+    int cfg;        // tile shape, see k_dw_gemm
     int a_row;      // first dY row in the workspace
     int b_row;      // first input row in the saved activations
     int M, N;       // valid output rows / columns (<= tile)
@@ -162,22 +163,22 @@ struct DwTask {
     int64_t bias;   // offset of the bias vector, or -1
 };
 struct DwTasks {
-    DwTask t[8];
+    DwTask t[16];
 };
 
 constexpr int KT = 32;           // points per K chunk
 constexpr int LDT = KT + 4;      // padded LDS row (floats): 16-byte aligned, conflict-free b128 reads
 
+constexpr int DW_THREADS = 512;
+
 template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(64 * WM * WN)
-k_dw_gemm(DwTasks tasks, int64_t ldp, const float* __restrict__ act, const float* __restrict__ scr_rows,
-          float* __restrict__ slabs, int64_t slab_stride) {
-    constexpr int NTHREADS = 64 * WM * WN, TILE_M = WM * TM * 32, TILE_N = WN * TN * 32;
+__device__ __forceinline__ void dw_body(const DwTask& task, int split, int64_t ldp, const float* __restrict__ act,
+                                        const float* __restrict__ scr_rows, float* __restrict__ slabs,
+                                        int64_t slab_stride, float* smem) {
+    static_assert(64 * WM * WN == DW_THREADS, "every tile shape uses all eight waves");
+    constexpr int NTHREADS = DW_THREADS, TILE_M = WM * TM * 32, TILE_N = WN * TN * 32;
     constexpr int ROWS = TILE_M + TILE_N;
     constexpr int LOADS = (ROWS * (KT / 4) + NTHREADS - 1) / NTHREADS;  // float4 per thread per chunk
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DwTask task = tasks.t[blockIdx.x / KSPLIT];
-    const int split = blockIdx.x % KSPLIT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
 
@@ -292,19 +293,28 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
     }
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_dw(const DwTasks& tasks, int n_tasks, int64_t ldp, const float* act, const float* scr_rows, float* slabs,
-              int64_t slab_stride, hipStream_t stream) {
-    constexpr int ROWS = (WM * TM + WN * TN) * 32;
-    const size_t lds = 2 * (size_t)ROWS * LDT * sizeof(float);
-    auto kernel = k_dw_gemm<WM, WN, TM, TN>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kernel, dim3(n_tasks * KSPLIT), dim3(64 * WM * WN), lds, stream, tasks, ldp, act, scr_rows, slabs,
-                       slab_stride);
-    return launched("nerf_mlp_bwd (dW)");
+// Tile shapes (rows of dY x rows of X per workgroup, eight waves each):
+//   0: 256x256  hidden layers, feature_linear      1: 256x64  encoded-position inputs of layers 0 and 5
+//   2: 128x256  views layer, feature inputs        3: 128x64  views layer, encoded directions (27 used)
+//   4:  64x128  rgb head (3 rows used)             5:  32x256 alpha / output_linear head
+// All tasks of a backward run in ONE launch, largest first, so the short ones fill the tail of the long ones.
+__global__ void __launch_bounds__(DW_THREADS)
+k_dw_gemm(DwTasks tasks, int64_t ldp, const float* __restrict__ act, const float* __restrict__ scr_rows,
+          float* __restrict__ slabs, int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DwTask task = tasks.t[blockIdx.x / KSPLIT];
+    const int split = blockIdx.x % KSPLIT;
+    switch (task.cfg) {
+        case 0: dw_body<2, 4, 4, 2>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
+        case 1: dw_body<8, 1, 1, 2>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
+        case 2: dw_body<2, 4, 2, 2>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
+        case 3: dw_body<4, 2, 1, 1>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
+        case 4: dw_body<2, 4, 1, 1>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
+        default: dw_body<1, 8, 1, 1>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
+    }
 }
+
+constexpr size_t DW_LDS_BYTES = 2 * (size_t)512 * LDT * sizeof(float);  // the 256x256 shape: 512 rows, two buffers
 
 }  // namespace
 
@@ -355,46 +365,31 @@ int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float
     int rc = launched("nerf_mlp_bwd (data)");
     if (rc) return rc;
 
-    // ---- dW = dY X^T, grouped by tile shape
-    DwTasks big{};   // 256 x 256
-    int nb = 0;
+    // ---- dW = dY X^T: one launch over all layers
+    DwTasks tk{};
+    int nt = 0;
     for (int l = 1; l < 8; ++l) {
         const int ldc = (l == 5) ? W + IN_PTS : W;
-        big.t[nb++] = DwTask{SCR_H0 + 256 * l, ACT_H0 + 256 * (l - 1), 256, 256, ldc, po.pts_w[l] + (l == 5 ? IN_PTS : 0), po.pts_b[l]};
+        tk.t[nt++] = DwTask{0, SCR_H0 + 256 * l, ACT_H0 + 256 * (l - 1), 256, 256, ldc, po.pts_w[l] + (l == 5 ? IN_PTS : 0), po.pts_b[l]};
     }
-    if (use_viewdirs) big.t[nb++] = DwTask{SCR_FEAT, ACT_H0 + 256 * 7, 256, 256, W, po.feat_w, po.feat_b};
-    rc = launch_dw<2, 4, 4, 2>(big, nb, ldp, act, scratch, slabs, slab, stream);
-    if (rc) return rc;
-
-    DwTasks enc{};   // 256 x 64: the encoded-position inputs of layers 0 and 5
-    enc.t[0] = DwTask{SCR_H0, ACT_ENC_PTS, 256, IN_PTS, IN_PTS, po.pts_w[0], po.pts_b[0]};
-    enc.t[1] = DwTask{SCR_H0 + 256 * 5, ACT_ENC_PTS, 256, IN_PTS, W + IN_PTS, po.pts_w[5], -1};
-    rc = launch_dw<8, 1, 1, 2>(enc, 2, ldp, act, scratch, slabs, slab, stream);
-    if (rc) return rc;
-
     if (use_viewdirs) {
-        DwTasks v{};     // 128 x 256 and 128 x 32: views layer
-        v.t[0] = DwTask{SCR_VIEWS, ACT_FEAT, 128, 256, po.views_in, po.views_w, po.views_b};
-        rc = launch_dw<2, 4, 2, 2>(v, 1, ldp, act, scratch, slabs, slab, stream);
-        if (rc) return rc;
-        DwTasks vd{};
-        vd.t[0] = DwTask{SCR_VIEWS, ACT_ENC_DIRS, 128, IN_DIRS, po.views_in, po.views_w + W, -1};
-        rc = launch_dw<4, 1, 1, 1>(vd, 1, ldp, act, scratch, slabs, slab, stream);
-        if (rc) return rc;
-        DwTasks hd{};    // 32 x 128 (rgb: head rows A) and 32 x 256 (alpha: head rows B)
-        hd.t[0] = DwTask{SCR_HEAD, ACT_VIEWS, 3, 128, W / 2, po.rgb_w, po.rgb_b};
-        rc = launch_dw<1, 4, 1, 1>(hd, 1, ldp, act, scratch, slabs, slab, stream);
-        if (rc) return rc;
-        DwTasks ha{};
-        ha.t[0] = DwTask{SCR_HEAD2, ACT_H0 + 256 * 7, 1, 256, W, po.alpha_w, po.alpha_b};
-        rc = launch_dw<1, 8, 1, 1>(ha, 1, ldp, act, scratch, slabs, slab, stream);
-        if (rc) return rc;
-    } else {
-        DwTasks ho{};    // output_linear: out_ch x 256
-        ho.t[0] = DwTask{SCR_HEAD, ACT_H0 + 256 * 7, output_ch, 256, W, po.out_w, po.out_b};
-        rc = launch_dw<1, 8, 1, 1>(ho, 1, ldp, act, scratch, slabs, slab, stream);
-        if (rc) return rc;
+        tk.t[nt++] = DwTask{0, SCR_FEAT, ACT_H0 + 256 * 7, 256, 256, W, po.feat_w, po.feat_b};
+        tk.t[nt++] = DwTask{2, SCR_VIEWS, ACT_FEAT, 128, 256, po.views_in, po.views_w, po.views_b};
     }
+    tk.t[nt++] = DwTask{1, SCR_H0, ACT_ENC_PTS, 256, IN_PTS, IN_PTS, po.pts_w[0], po.pts_b[0]};
+    tk.t[nt++] = DwTask{1, SCR_H0 + 256 * 5, ACT_ENC_PTS, 256, IN_PTS, W + IN_PTS, po.pts_w[5], -1};
+    if (use_viewdirs) {
+        tk.t[nt++] = DwTask{5, SCR_HEAD2, ACT_H0 + 256 * 7, 1, 256, W, po.alpha_w, po.alpha_b};
+        tk.t[nt++] = DwTask{3, SCR_VIEWS, ACT_ENC_DIRS, 128, IN_DIRS, po.views_in, po.views_w + W, -1};
+        tk.t[nt++] = DwTask{4, SCR_HEAD, ACT_VIEWS, 3, 128, W / 2, po.rgb_w, po.rgb_b};
+    } else {
+        tk.t[nt++] = DwTask{5, SCR_HEAD, ACT_H0 + 256 * 7, output_ch, 256, W, po.out_w, po.out_b};
+    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_LDS_BYTES);
+    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_dw_gemm, dim3(nt * KSPLIT), dim3(DW_THREADS), DW_LDS_BYTES, stream, tk, ldp, act, scratch, slabs, slab);
+    rc = launched("nerf_mlp_bwd (dW)");
+    if (rc) return rc;
 
     hipLaunchKernelGGL(k_reduce_slabs, dim3(1024), dim3(256), 0, stream, slabs, slab, po.total, d_params);
     return launched("nerf_mlp_bwd (reduce)");

@@ -222,6 +222,26 @@ __global__ void __launch_bounds__(256) k_pack(int use_viewdirs, int output_ch, c
     }
 }
 
+// The source map is pure index arithmetic but costs a few hundred instructions per element; training repacks
+// after every optimiser step, so the map is materialised once per model and the repack is a plain gather.
+__global__ void __launch_bounds__(256) k_pack_table(int use_viewdirs, int output_ch, int32_t* __restrict__ table,
+                                                    int64_t n_fwd, int64_t n_bwd) {
+    const int64_t total = n_fwd + n_bwd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        table[i] = (int32_t)(i < n_fwd ? fwd_source(use_viewdirs, output_ch, i) : bwd_source(use_viewdirs, output_ch, i - n_fwd));
+}
+
+__global__ void __launch_bounds__(256) k_pack_gather(const int32_t* __restrict__ table, const float* __restrict__ params,
+                                                     float* __restrict__ fwd, int64_t n_fwd, float* __restrict__ bwd,
+                                                     int64_t n_bwd) {
+    const int64_t total = n_fwd + n_bwd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = table[i];
+        const float v = s < 0 ? 0.0f : params[s];
+        if (i < n_fwd) fwd[i] = v; else bwd[i - n_fwd] = v;
+    }
+}
+
 constexpr size_t FWD_LDS_BYTES = (RING_FLOATS + AUX_FLOATS) * sizeof(float);
 
 }  // namespace
@@ -255,6 +275,22 @@ int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, floa
     hipLaunchKernelGGL(k_pack, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, params, packed_fwd,
                        nf, packed_bwd, nb);
     return launched("nerf_pack_weights");
+}
+
+int nerf_pack_table(int use_viewdirs, int output_ch, int32_t* table, void* stream) {
+    NERF_REQUIRE(table, "nerf_pack_table: null pointer");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_pack_table: output_ch=%d not in 1..8", output_ch);
+    hipLaunchKernelGGL(k_pack_table, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, table,
+                       fwd_packed_floats(use_viewdirs), bwd_packed_floats(use_viewdirs));
+    return launched("nerf_pack_table");
+}
+
+int nerf_pack_weights_table(int use_viewdirs, const int32_t* table, const float* params, float* packed_fwd,
+                            float* packed_bwd, void* stream) {
+    NERF_REQUIRE(table && params && packed_fwd, "nerf_pack_weights_table: null pointer");
+    const int64_t nf = fwd_packed_floats(use_viewdirs), nb = packed_bwd ? bwd_packed_floats(use_viewdirs) : 0;
+    hipLaunchKernelGGL(k_pack_gather, dim3(1024), dim3(256), 0, as_stream(stream), table, params, packed_fwd, nf, packed_bwd, nb);
+    return launched("nerf_pack_weights_table");
 }
 
 int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,

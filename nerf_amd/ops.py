@@ -225,14 +225,27 @@ def mlp_n_params(use_viewdirs: bool, output_ch: int) -> int:
     return lib.nerf_mlp_n_params(int(use_viewdirs), output_ch)
 
 
-def pack_weights(flat: torch.Tensor, use_viewdirs: bool, output_ch: int, want_bwd: bool):
+def pack_table(use_viewdirs: bool, output_ch: int, dev) -> torch.Tensor:
+    """int32 source map of the packed streams (forward entries, then the transposed stream's)."""
+    n = lib.nerf_mlp_packed_floats(int(use_viewdirs)) + lib.nerf_mlp_packed_bwd_floats(int(use_viewdirs))
+    table = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nerf_pack_table(int(use_viewdirs), output_ch, table.data_ptr(), _stream()))
+    return table
+
+
+def pack_weights(flat: torch.Tensor, use_viewdirs: bool, output_ch: int, want_bwd: bool, table: Optional[torch.Tensor] = None):
     flat = _f32c(flat, "params")
     assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
     fwd = torch.empty(lib.nerf_mlp_packed_floats(int(use_viewdirs)), dtype=torch.float32, device=flat.device)
     bwd = (torch.empty(lib.nerf_mlp_packed_bwd_floats(int(use_viewdirs)), dtype=torch.float32, device=flat.device)
            if want_bwd else None)
     with torch.cuda.device(flat.device):
-        check(lib.nerf_pack_weights(int(use_viewdirs), output_ch, flat.data_ptr(), fwd.data_ptr(), _ptr(bwd), _stream()))
+        if table is None:
+            check(lib.nerf_pack_weights(int(use_viewdirs), output_ch, flat.data_ptr(), fwd.data_ptr(), _ptr(bwd), _stream()))
+        else:
+            check(lib.nerf_pack_weights_table(int(use_viewdirs), table.data_ptr(), flat.data_ptr(), fwd.data_ptr(), _ptr(bwd),
+                                              _stream()))
     return fwd, bwd
 
 

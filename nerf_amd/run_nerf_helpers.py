@@ -90,6 +90,7 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(W, output_ch)
         self._pack_key = None
         self._pack = None
+        self._pack_table = None
 
     # -- kernel plumbing ---------------------------------------------------------------------------
     def _check_arch(self):
@@ -112,7 +113,9 @@ class NeRF(nn.Module):
                 flat = torch.cat([p.detach().reshape(-1) for p in params])
                 if not flat.is_cuda:
                     raise RuntimeError("NeRF parameters must live on a HIP device (call .to('cuda'))")
-                fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd)
+                if self._pack_table is None or self._pack_table.device != flat.device:
+                    self._pack_table = ops.pack_table(self.use_viewdirs, self.output_ch, flat.device)
+                fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd, self._pack_table)
             self._pack, self._pack_key = (fwd, bwd, flat), key
         return self._pack
 
