@@ -296,8 +296,7 @@ class _FusedMLP(torch.autograd.Function):
     """raw = NeRF(encode(pts), encode(viewdirs)); gradients flow to the parameters only."""
 
     @staticmethod
-    def forward(ctx, pts, viewdirs, model, pts_per_ray, *params):
-        need_grad = any(ctx.needs_input_grad[4:])  # grad mode is off inside forward(); autograd tells us here
+    def forward(ctx, pts, viewdirs, model, pts_per_ray, need_grad, *params):
         fwd, bwd, flat = model._packed(need_grad)
         n_pts = pts.numel() // 3
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
@@ -314,8 +313,11 @@ class _FusedMLP(torch.autograd.Function):
         model = ctx.model
         d_flat = mlp_backward(d_out, act, flat, bwd, fwd, model.use_viewdirs, model.output_ch, ctx.pts_per_ray)
         grads = model._split_flat(d_flat)
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_per_ray: int) -> torch.Tensor:
-    return _FusedMLP.apply(pts, viewdirs, model, pts_per_ray, *model.parameters())
+    params = list(model.parameters())
+    # decided here, where the caller's grad mode is visible: under no_grad (rendering) nothing is saved
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _FusedMLP.apply(pts, viewdirs, model, pts_per_ray, need_grad, *params)
