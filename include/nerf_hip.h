@@ -139,6 +139,11 @@ int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* 
                  int use_viewdirs, int output_ch, const float* packed_fwd, float* out, float* act,
                  void* stream);
 
+/* NeRF.forward exactly as upstream calls it (run_nerf_helpers.py:109-133): x [n_pts, 63 (+27)] holds
+ * already-encoded inputs (positions, then directions when the network has a view branch). */
+int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int output_ch,
+                         const float* packed_fwd, float* out, float* act, void* stream);
+
 /* Backward of nerf_mlp_fwd w.r.t. the parameters (inputs carry no gradient upstream:
  * run_nerf.py:467 detaches the samples).  d_out [n_pts,out_ch]; act from the forward;
  * packed_fwd / packed_bwd from nerf_pack_weights; scratch: nerf_mlp_scratch_floats() floats of

@@ -46,6 +46,7 @@ SIGNATURES = {
     "nerf_pack_table": (_i, [_i, _i, _p, _p]),
     "nerf_pack_weights_table": (_i, [_i, _p, _p, _p, _p, _p]),
     "nerf_mlp_fwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "nerf_mlp_fwd_encoded": (_i, [_l, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_mlp_bwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
 }
 

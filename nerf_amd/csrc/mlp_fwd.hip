@@ -77,7 +77,7 @@ __device__ __forceinline__ float head_dot(const f32x16 (&A)[8], const float* w_l
 
 __device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
 
-template <bool VIEWDIRS, bool SAVE>
+template <bool VIEWDIRS, bool SAVE, bool ENCODED>
 __global__ void __launch_bounds__(THREADS, 1)
 k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
           int output_ch, const float* __restrict__ packed, float* __restrict__ out, float* __restrict__ act) {
@@ -102,7 +102,24 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
 
     // ---- positional encoding into register tiles (slot maps: mlp_layout.hpp)
     f32x16 E[2], D;
-    {
+    if constexpr (ENCODED) {
+        // pts is the reference's pre-encoded input [n_pts, 63 (+27)]; pts_per_ray carries its row length
+        const float* row = pts + pl * pts_per_ray;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int f0 = enc_pts_feature(s, 0), f1 = enc_pts_feature(s, 1);
+            const float v = (h && f1 < 0) ? 0.0f : row[h ? f1 : f0];
+            if (s < 16) E[0][s] = v; else E[1][s - 16] = v;
+        }
+        if (VIEWDIRS) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int f0 = enc_dirs_feature(s, 0), f1 = enc_dirs_feature(s, 1);
+                const int f = h ? f1 : f0;
+                D[s] = (s >= 14 || (h && f1 < 0)) ? 0.0f : row[IN_PTS + (f < 0 ? 0 : f)];
+            }
+        }
+    } else {
         const float x0 = pts[pl * 3 + 0], x1 = pts[pl * 3 + 1], x2 = pts[pl * 3 + 2];
         E[0][0] = h ? x2 : x0;
         E[0][1] = h ? 0.0f : x1;
@@ -132,6 +149,8 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
             D[14] = 0.0f;
             D[15] = 0.0f;
         }
+    }
+    {
         if constexpr (save) {
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
@@ -313,8 +332,32 @@ int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* 
                            vd, och, packed_fwd, out, act);
         return launched("nerf_mlp_fwd");
     };
-    if (use_viewdirs) return act ? go(k_mlp_fwd<true, true>, pts_per_ray, viewdirs, 4) : go(k_mlp_fwd<true, false>, pts_per_ray, viewdirs, 4);
-    return act ? go(k_mlp_fwd<false, true>, 1, nullptr, output_ch) : go(k_mlp_fwd<false, false>, 1, nullptr, output_ch);
+    if (use_viewdirs) return act ? go(k_mlp_fwd<true, true, false>, pts_per_ray, viewdirs, 4) : go(k_mlp_fwd<true, false, false>, pts_per_ray, viewdirs, 4);
+    return act ? go(k_mlp_fwd<false, true, false>, 1, nullptr, output_ch) : go(k_mlp_fwd<false, false, false>, 1, nullptr, output_ch);
+}
+
+int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int output_ch, const float* packed_fwd,
+                         float* out, float* act, void* stream) {
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd_encoded: n_pts=%lld", (long long)n_pts);
+    if (n_pts == 0) return 0;
+    NERF_REQUIRE(x && packed_fwd && out, "nerf_mlp_fwd_encoded: null pointer");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_fwd_encoded: output_ch=%d not in 1..8", output_ch);
+    NERF_REQUIRE((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                 "nerf_mlp_fwd_encoded: packed_fwd and out must be 16-byte aligned");
+    const int64_t blocks = (n_pts + TILE_PTS - 1) / TILE_PTS;
+    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_encoded: n_pts=%lld too large for one launch", (long long)n_pts);
+    NERF_REQUIRE(!act || padded_points(n_pts) * 4 * 5 < (int64_t)0xffffffff, "nerf_mlp_fwd_encoded: n_pts=%lld too large to save activations in one call", (long long)n_pts);
+    const int ldx = IN_PTS + (use_viewdirs ? IN_DIRS : 0);
+    auto go = [&](auto kernel, int och) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)FWD_LDS_BYTES);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_encoded: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), FWD_LDS_BYTES, as_stream(stream), n_pts, ldx, x,
+                           (const float*)nullptr, och, packed_fwd, out, act);
+        return launched("nerf_mlp_fwd_encoded");
+    };
+    if (use_viewdirs) return act ? go(k_mlp_fwd<true, true, true>, 4) : go(k_mlp_fwd<true, false, true>, 4);
+    return act ? go(k_mlp_fwd<false, true, true>, output_ch) : go(k_mlp_fwd<false, false, true>, output_ch);
 }
 
 }  // extern "C"

@@ -251,9 +251,19 @@ def pack_weights(flat: torch.Tensor, use_viewdirs: bool, output_ch: int, want_bw
 
 def mlp_forward(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_fwd: torch.Tensor, use_viewdirs: bool,
                 output_ch: int, pts_per_ray: int, act: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pts_per_ray > 0: pts are raw positions [P,3] (+ per-ray viewdirs); pts_per_ray == 0: pts are pre-encoded rows."""
     pts = _f32c(pts, "pts")
-    n_pts = pts.numel() // 3
     out_ch = 4 if use_viewdirs else output_ch
+    if pts_per_ray == 0:
+        width = 63 + (27 if use_viewdirs else 0)
+        assert pts.shape[-1] == width, (pts.shape, width)
+        n_pts = pts.numel() // width
+        out = torch.empty((n_pts, out_ch), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            check(lib.nerf_mlp_fwd_encoded(n_pts, pts.data_ptr(), int(use_viewdirs), output_ch, packed_fwd.data_ptr(),
+                                           out.data_ptr(), _ptr(act), _stream()))
+        return out
+    n_pts = pts.numel() // 3
     out = torch.empty((n_pts, out_ch), dtype=torch.float32, device=pts.device)
     if use_viewdirs:
         viewdirs = _f32c(viewdirs, "viewdirs")
@@ -298,7 +308,7 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, viewdirs, model, pts_per_ray, need_grad, *params):
         fwd, bwd, flat = model._packed(need_grad)
-        n_pts = pts.numel() // 3
+        n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
         out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
         if need_grad:

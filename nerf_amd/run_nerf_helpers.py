@@ -131,9 +131,12 @@ class NeRF(nn.Module):
         return ops.fused_mlp(pts, viewdirs if self.use_viewdirs else None, self, pts_per_ray)
 
     def forward(self, x):
-        """x: already-encoded inputs [..., input_ch + input_ch_views], as upstream."""
-        raise NotImplementedError("NeRF.forward on pre-encoded inputs: use run_network / NeRF.query, which fuse the "
-                                  "encoding into the kernel")
+        """x: already-encoded inputs [..., input_ch + input_ch_views], as upstream (run_nerf_helpers.py:109-133).
+        The render path does not come through here (run_network fuses the encoding); gradients flow to the
+        parameters only."""
+        x = ops.to_dev(x)
+        out = ops.fused_mlp(x.reshape(-1, x.shape[-1]), None, self, 0)
+        return out.reshape(list(x.shape[:-1]) + [out.shape[-1]])
 
     def load_weights_from_keras(self, weights):
         """run_nerf_helpers.py:136-163."""
