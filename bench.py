@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--res", type=int, default=800, help="image side; 800 is the benchmark configuration")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,6 +222,28 @@ def main():
                                   "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
                       "parallelism": f"ray/view-sharded x{world}, no collective"},
            "roofline": roofline}
+
+    if not args.no_bf16:
+        # the bf16-operand / fp32-accumulate variant of the same render (reduced precision: reported, never `value`)
+        for m in models:
+            m.mlp_dtype = 'bf16'
+        step(0)
+        ops.PROFILE = []
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        sync()
+        dt16 = time.perf_counter() - t0
+        prof16, ops.PROFILE = ops.PROFILE, None
+        for m in models:
+            m.mlp_dtype = 'f32'
+        k16 = [(n, s.elapsed_time(e) * 1e-3) for (name, n, s, e) in prof16 if name == "mlp_fwd_bf16"]
+        s16 = sum(t for _, t in k16)
+        out["render_bf16"] = {"rays_per_s": round(rays_per_step * args.steps / dt16, 1), "ms_per_step": round(1e3 * dt16 / args.steps, 3),
+                              "mlp_tflops_algorithmic": round(sum(n for n, _ in k16) * FLOP_PER_POINT_FWD / s16 / 1e12, 1) if s16 > 0 else None,
+                              "mlp_share_of_step": round(s16 / dt16, 4), "dtype": "bf16 operands, f32 accumulate",
+                              "note": "per-GPU, this rank only; tolerance vs fp32: raw within 2e-2 of scale, rgb within 1e-2"}
 
     if not args.no_train:
         # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)

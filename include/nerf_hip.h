@@ -144,6 +144,15 @@ int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* 
 int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int output_ch,
                          const float* packed_fwd, float* out, float* act, void* stream);
 
+/* bf16-operand / fp32-accumulate inference variant of nerf_mlp_fwd (same arguments and outputs).
+ * packed_bf16: nerf_mlp_packed_bf16_bytes() bytes built by nerf_pack_weights_bf16 from the fp32
+ * forward stream.  Every product's inputs are rounded to bf16 (8 significant bits), sums and heads
+ * are fp32: raw outputs agree with the fp32 path to about 1e-2 of their scale. */
+int64_t nerf_mlp_packed_bf16_bytes(int use_viewdirs);
+int nerf_pack_weights_bf16(int use_viewdirs, const float* packed_fwd, void* packed_bf16, void* stream);
+int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
+                      int use_viewdirs, int output_ch, const void* packed_bf16, float* out, void* stream);
+
 /* Backward of nerf_mlp_fwd w.r.t. the parameters (inputs carry no gradient upstream:
  * run_nerf.py:467 detaches the samples).  d_out [n_pts,out_ch]; act from the forward;
  * packed_fwd / packed_bwd from nerf_pack_weights; scratch: nerf_mlp_scratch_floats() floats of

@@ -280,6 +280,34 @@ def mlp_forward(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_fwd:
     return out
 
 
+def pack_weights_bf16(packed_fwd: torch.Tensor, use_viewdirs: bool) -> torch.Tensor:
+    out = torch.empty(lib.nerf_mlp_packed_bf16_bytes(int(use_viewdirs)), dtype=torch.uint8, device=packed_fwd.device)
+    with torch.cuda.device(packed_fwd.device):
+        check(lib.nerf_pack_weights_bf16(int(use_viewdirs), packed_fwd.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def mlp_forward_bf16(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_bf16: torch.Tensor, use_viewdirs: bool,
+                     output_ch: int, pts_per_ray: int) -> torch.Tensor:
+    """bf16-operand / fp32-accumulate inference variant (raw outputs within ~1e-2 of their scale of the fp32 path)."""
+    pts = _f32c(pts, "pts")
+    n_pts = pts.numel() // 3
+    out = torch.empty((n_pts, 4 if use_viewdirs else output_ch), dtype=torch.float32, device=pts.device)
+    if use_viewdirs:
+        viewdirs = _f32c(viewdirs, "viewdirs")
+        assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
+    with torch.cuda.device(pts.device):
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        check(lib.nerf_mlp_fwd_bf16(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
+                                    int(use_viewdirs), output_ch, packed_bf16.data_ptr(), out.data_ptr(), _stream()))
+        if PROFILE is not None:
+            ev1.record()
+            PROFILE.append(("mlp_fwd_bf16", n_pts, ev0, ev1))
+    return out
+
+
 def mlp_act_buffer(n_pts: int, use_viewdirs: bool, dev) -> torch.Tensor:
     return torch.empty(lib.nerf_mlp_act_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=dev)
 
@@ -330,4 +358,6 @@ def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_pe
     params = list(model.parameters())
     # decided here, where the caller's grad mode is visible: under no_grad (rendering) nothing is saved
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    if not need_grad and getattr(model, "mlp_dtype", "f32") == "bf16" and pts_per_ray > 0:
+        return mlp_forward_bf16(pts, viewdirs, model._packed_bf16(), model.use_viewdirs, model.output_ch, pts_per_ray)
     return _FusedMLP.apply(pts, viewdirs, model, pts_per_ray, need_grad, *params)

@@ -91,6 +91,10 @@ class NeRF(nn.Module):
         self._pack_key = None
         self._pack = None
         self._pack_table = None
+        self._pack16 = None
+        # 'f32' (default; fp32 MFMA, the reference's precision) or 'bf16' (no-grad queries only: bf16 operands,
+        # fp32 accumulation, raw outputs within ~1e-2 of their scale; training always runs fp32)
+        self.mlp_dtype = 'f32'
 
     # -- kernel plumbing ---------------------------------------------------------------------------
     def _check_arch(self):
@@ -117,7 +121,14 @@ class NeRF(nn.Module):
                     self._pack_table = ops.pack_table(self.use_viewdirs, self.output_ch, flat.device)
                 fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd, self._pack_table)
             self._pack, self._pack_key = (fwd, bwd, flat), key
+            self._pack16 = None
         return self._pack
+
+    def _packed_bf16(self):
+        fwd = self._packed(False)[0]
+        if self._pack16 is None:
+            self._pack16 = ops.pack_weights_bf16(fwd, self.use_viewdirs)
+        return self._pack16
 
     def _split_flat(self, flat: torch.Tensor):
         out, off = [], 0

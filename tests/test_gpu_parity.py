@@ -577,3 +577,56 @@ def test_data_parallel_gradient_equals_full_batch(device):
     avg = sum(shards) / world
     scale = float(full.abs().max())
     assert float((avg - full).abs().max()) <= 5e-5 * scale
+
+
+def test_bf16_variant_within_stated_tolerance(device):
+    """mlp_dtype='bf16': every product's inputs rounded to bf16, fp32 sums.  Stated tolerance against the fp32
+    oracle: raw outputs within 2e-2 of the tensor's scale (max |x|), rendered rgb/acc within 1e-2 absolute."""
+    from nerf_amd.run_nerf import render
+    rng = np.random.Generator(np.random.PCG64(12))
+    qf = _query_fn()
+    sd = _peaky(O.random_state_dict(33), 30.0)
+    m = _model(sd, device)
+    m.mlp_dtype = 'bf16'
+    for n, s in ((1, 1), (129, 3), (100, 192), (37, 64)):
+        pts = T(rng.uniform(-5, 5, size=(n, s, 3)).astype(np.float32))
+        vd = T(rng.normal(size=(n, 3)).astype(np.float32))
+        vd = vd / vd.norm(dim=-1, keepdim=True)
+        with torch.no_grad():
+            raw = qf(pts.to(device), vd.to(device), m).cpu()
+            want = O.query_field(pts, vd, sd)
+        for ch in range(4):
+            scale = float(want[..., ch].abs().max())
+            err = float((raw[..., ch] - want[..., ch]).abs().max())
+            assert err <= 2e-2 * max(scale, 1e-3), (n, s, ch, err, scale)
+    # no view branch
+    sd2 = O.random_state_dict(22, use_viewdirs=False)
+    sd2 = {k: v for k, v in sd2.items() if not k.startswith("views_linears")}
+    from nerf_amd.run_nerf_helpers import NeRF
+    m2 = NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+    m2.load_state_dict(sd2, strict=False)
+    m2 = m2.to(device)
+    m2.mlp_dtype = 'bf16'
+    pts = T(rng.uniform(-4, 4, size=(50, 9, 3)).astype(np.float32))
+    with torch.no_grad():
+        raw2 = qf(pts.to(device), None, m2).cpu()
+        want2 = O.query_field(pts, None, sd2)
+    assert float((raw2 - want2).abs().max()) <= 2e-2 * float(want2.abs().max())
+    # rendered image vs the reference fixture
+    g = golden("image")
+    mc = _model(_peaky(O.random_state_dict(31), 40.0), device)
+    mf = _model(_peaky(O.random_state_dict(32), 60.0), device)
+    mc.mlp_dtype = mf.mlp_dtype = 'bf16'
+    H, W, f = g["hwf"]
+    H, W = int(H), int(W)
+    K = np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]])
+    kw = dict(network_fn=mc, network_query_fn=qf, N_samples=64, N_importance=128, network_fine=mf, perturb=0.0,
+              white_bkgd=True, use_viewdirs=True, ndc=False, near=2.0, far=6.0)
+    with torch.no_grad():
+        rgb, disp, acc, _ = render(H, W, K, chunk=1 << 15, c2w=T(g["pose"]).to(device), **kw)
+    assert float(np.abs(rgb.cpu().numpy() - g["rgb"]).max()) <= 1e-2
+    assert float(np.abs(acc.cpu().numpy() - g["acc"]).max()) <= 1e-2
+    # gradients still flow through the fp32 path when the model is in bf16 mode
+    raw = qf(pts.to(device)[:4], None, m2)
+    raw.sum().backward()
+    assert m2.pts_linears[0].weight.grad is not None
