@@ -78,6 +78,50 @@ def cpu_baseline(sds, pose, H, W, K, n_rays):
     return n_rays / dt, out, pick
 
 
+def cpu_train_baseline(sds, n_rand, steps):
+    """The oracle's optimisation step (forward with jitter, two MSE terms, autograd backward, Adam) on n_rand rays."""
+    from oracle import nerf_oracle as O
+    H = W = 400
+    K = lego_camera(H, W)
+    rng = np.random.Generator(np.random.PCG64(5))
+    pc = {k: v.clone().requires_grad_(True) for k, v in sds[0].items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in sds[1].items()}
+    params = list(pc.values()) + list(pf.values())
+    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
+    o, d = O.pixel_rays(H, W, K, O.orbit_pose(30.0, -30.0, 4.0)[:3, :4])
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        pick = torch.from_numpy(rng.choice(H * W, size=n_rand, replace=False))
+        rays = O.pack_rays(o.reshape(-1, 3)[pick], d.reshape(-1, 3)[pick], 2., 6., use_viewdirs=True)
+        target = torch.from_numpy(rng.uniform(0, 1, size=(n_rand, 3)).astype(np.float32))
+        got = O.render_chunks(rays, 1 << 15, sd_coarse=pc, sd_fine=pf, n_coarse=64, n_fine=128, perturb=1.0, white_bkgd=True,
+                              t_rand=torch.rand(n_rand, 64), u=torch.rand(n_rand, 128), retraw=True)
+        opt.zero_grad()
+        loss = O.mse(got["rgb_map"], target) + O.mse(got["rgb0"], target)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    return n_rand * steps / sum(times[1:])
+
+
+HBM_PEAK_GBS = 8000.0
+
+
+def hbm_kernels(prof):
+    """Achieved algorithmic GB/s of the streaming kernels (ops records their algorithmic bytes per launch)."""
+    agg = {}
+    for name, units, s, e in prof:
+        if name.startswith("mlp_"):
+            continue
+        a = agg.setdefault(name, [0, 0.0, 0])
+        a[0] += units
+        a[1] += s.elapsed_time(e) * 1e-3
+        a[2] += 1
+    return {k: {"launches": c, "mean_us": round(1e6 * t / c, 1), "GBps_algorithmic": round(b / t / 1e9, 1),
+                "frac_of_hbm_peak": round(b / t / 1e9 / HBM_PEAK_GBS, 4)} for k, (b, t, c) in agg.items() if t > 0}
+
+
 def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
     """The upstream optimisation step (run_nerf.py:826-883, no_batching mode) on synthetic targets: rays of one
     400x400 view, n_rand random pixels, render with jitter, two MSE terms, backward, (all-reduce,) Adam, lr decay."""
@@ -134,12 +178,13 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
     with torch.no_grad():
         for p, s0 in zip(params, saved):
             p.copy_(s0)
-    kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in ("mlp_fwd", "mlp_bwd"))
+    kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in ("mlp_fwd_save", "mlp_bwd"))
     flop = n_rand * 256 * FLOP_PER_POINT_TRAIN * steps
     return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "n_rand_per_gpu": n_rand,
             "steps": steps, "final_loss": float(loss), "mlp_kernels_share_of_step": round(kern / dt, 4),
             "mlp_tflops_algorithmic": round(flop / kern / 1e12, 2) if kern > 0 else None,
-            "frac_of_fp32_matrix_peak": round(flop / kern / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if kern > 0 else None}
+            "frac_of_fp32_matrix_peak": round(flop / kern / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if kern > 0 else None,
+            "hbm_kernels": hbm_kernels(prof)}
 
 
 def main():
@@ -221,7 +266,7 @@ def main():
            "config": {"workload": f"lego {H}x{W} render_only, N_samples=64, N_importance=128, chunk={chunk}, white_bkgd, "
                                   "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
                       "parallelism": f"ray/view-sharded x{world}, no collective"},
-           "roofline": roofline}
+           "roofline": roofline, "hbm_kernels": hbm_kernels(prof)}
 
     if not args.no_bf16:
         # the bf16-operand / fp32-accumulate variant of the same render (reduced precision: reported, never `value`)
@@ -259,6 +304,11 @@ def main():
                                    "kind": "port", "sample": f"{args.cpu_rays} random rays of the last benchmark view, "
                                    "same weights, PyTorch-CPU oracle", "host_cpus": os.cpu_count(),
                                    "max_abs_rgb_diff_vs_gpu": err, "speedup_per_gpu": round(value / world / cpu_rps, 1)}
+            if not args.no_train:
+                cpu_train = cpu_train_baseline(sds, 1024, 2)
+                out["cpu_baseline"]["train_rays_per_s"] = round(cpu_train, 1)
+                out["cpu_baseline"]["train_sample"] = "2 timed steps (after 1 warm-up) of the oracle's train step, N_rand=1024, 64+128 samples"
+                out["cpu_baseline"]["train_speedup_per_gpu"] = round(out["train"]["rays_per_s"] / world / cpu_train, 1)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

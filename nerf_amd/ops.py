@@ -14,7 +14,29 @@ from ._lib import check, lib
 
 
 # When set to a list, kernel launches append (name, units, start_event, end_event) recorded on the launch stream.
+# units: sample points for the MLP kernels, algorithmic HBM bytes for the streaming kernels.
 PROFILE = None
+
+
+class _timed:
+    """Brackets one launch with HIP events on the current stream when PROFILE is a list; free otherwise."""
+    __slots__ = ("name", "units", "ev0")
+
+    def __init__(self, name, units):
+        self.name, self.units, self.ev0 = name, units, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.ev0 = torch.cuda.Event(enable_timing=True)
+            self.ev0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev0 is not None and PROFILE is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            PROFILE.append((self.name, self.units, self.ev0, ev1))
+        return False
 
 
 def device() -> torch.device:
@@ -55,7 +77,7 @@ def get_rays(H: int, W: int, fx: float, fy: float, cx: float, cy: float, c2w: to
     c2w = _f32c(to_dev(c2w)[:3, :4], "c2w")
     o = torch.empty((H, W, 3), dtype=torch.float32, device=c2w.device)
     d = torch.empty_like(o)
-    with torch.cuda.device(c2w.device):
+    with torch.cuda.device(c2w.device), _timed("get_rays", 24 * H * W):
         check(lib.nerf_get_rays(H, W, fx, fy, cx, cy, c2w.data_ptr(), o.data_ptr(), d.data_ptr(), _stream()))
     return o, d
 
@@ -98,7 +120,7 @@ def pack_rays(rays_o, rays_d, near, far, viewdir_src=None, ndc=None):
     near_s, near_v = bound(near)
     far_s, far_v = bound(far)
     sx, sy, nn = ndc if ndc is not None else (0.0, 0.0, 0.0)
-    with torch.cuda.device(o.device):
+    with torch.cuda.device(o.device), _timed("pack_rays", n * (24 + 4 * ld + (48 if ndc is not None else 0))):
         check(lib.nerf_pack_rays(n, o.data_ptr(), d.data_ptr(), _ptr(vd), int(ndc is not None), sx, sy, nn, near_s, far_s,
                                  _ptr(near_v), _ptr(far_v), out.data_ptr(), ld, _stream()))
     return out
@@ -127,7 +149,8 @@ def sample_coarse(rays: torch.Tensor, t_vals: torch.Tensor, t_rand: Optional[tor
     if t_rand is not None:
         t_rand = _f32c(t_rand, "t_rand")
         assert t_rand.shape == (n, S)
-    with torch.cuda.device(rays.device):
+    # ray record in; z (4 B) + position (12 B) per sample out (+ 4 B per sample of jitter in)
+    with torch.cuda.device(rays.device), _timed("sample_coarse", n * (4 * ld + S * (16 + (4 if t_rand is not None else 0)))):
         check(lib.nerf_sample_coarse(n, S, rays.data_ptr(), ld, _f32c(t_vals, "t_vals").data_ptr(), _ptr(t_rand),
                                      int(bool(lindisp)), z.data_ptr(), pts.data_ptr(), _stream()))
     return z, pts
@@ -159,7 +182,9 @@ def sample_fine(z: torch.Tensor, weights: torch.Tensor, u: torch.Tensor, rays: O
     if want_pts:
         rays = _f32c(rays, "rays")
         ld = rays.shape[1]
-    with torch.cuda.device(dev):
+    # coarse z + weights in (8 B per coarse sample), own uniforms in, merged z out (+ 12 B positions per merged sample)
+    nbytes = n * (8 * Sc + (0 if shared else 4 * Si) + 4 * (Sc + Si) + 4 + ((4 * ld + 12 * (Sc + Si)) if want_pts else 0))
+    with torch.cuda.device(dev), _timed("sample_fine", nbytes):
         check(lib.nerf_sample_fine(n, Sc, Si, z.data_ptr(), weights.data_ptr(), u.data_ptr(), int(shared),
                                    _ptr(rays) if want_pts else None, ld, out["z"].data_ptr(), _ptr(out["pts"]),
                                    out["z_std"].data_ptr(), _ptr(out["samples"]), _ptr(out["inds"]), _stream()))
@@ -188,7 +213,7 @@ class _Composite(torch.autograd.Function):
         acc = torch.empty_like(disp)
         depth = torch.empty_like(disp)
         weights = torch.empty((n, S), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed("composite_fwd", n * (S * (24 + (4 if noise is not None else 0)) + 36)):
             check(lib.nerf_composite_fwd(n, S, raw.data_ptr(), z.data_ptr(), rays.data_ptr(), rays.stride(0), _ptr(noise),
                                          int(bool(white_bkgd)), rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(),
                                          weights.data_ptr(), depth.data_ptr(), _stream()))
@@ -205,7 +230,7 @@ class _Composite(torch.autograd.Function):
         def g(t):
             return None if t is None else _f32c(t, "grad")
         g_rgb, g_disp, g_acc, g_weights, g_depth = g(g_rgb), g(g_disp), g(g_acc), g(g_weights), g(g_depth)
-        with torch.cuda.device(raw.device):
+        with torch.cuda.device(raw.device), _timed("composite_bwd", n * (S * (36 + (4 if noise is not None else 0)) + 24)):
             check(lib.nerf_composite_bwd(n, S, raw.data_ptr(), z.data_ptr(), rays.data_ptr(), rays.stride(0), _ptr(noise),
                                          int(ctx.white), weights.data_ptr(), _ptr(g_rgb), _ptr(g_disp), _ptr(g_acc),
                                          _ptr(g_weights), _ptr(g_depth), d_raw.data_ptr(), _stream()))
@@ -268,15 +293,9 @@ def mlp_forward(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_fwd:
     if use_viewdirs:
         viewdirs = _f32c(viewdirs, "viewdirs")
         assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
-    with torch.cuda.device(pts.device):
-        if PROFILE is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
+    with torch.cuda.device(pts.device), _timed("mlp_fwd" if act is None else "mlp_fwd_save", n_pts):
         check(lib.nerf_mlp_fwd(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
                                int(use_viewdirs), output_ch, packed_fwd.data_ptr(), out.data_ptr(), _ptr(act), _stream()))
-        if PROFILE is not None:
-            ev1.record()
-            PROFILE.append(("mlp_fwd", n_pts, ev0, ev1))
     return out
 
 
@@ -296,15 +315,9 @@ def mlp_forward_bf16(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed
     if use_viewdirs:
         viewdirs = _f32c(viewdirs, "viewdirs")
         assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
-    with torch.cuda.device(pts.device):
-        if PROFILE is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
+    with torch.cuda.device(pts.device), _timed("mlp_fwd_bf16", n_pts):
         check(lib.nerf_mlp_fwd_bf16(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
                                     int(use_viewdirs), output_ch, packed_bf16.data_ptr(), out.data_ptr(), _stream()))
-        if PROFILE is not None:
-            ev1.record()
-            PROFILE.append(("mlp_fwd_bf16", n_pts, ev0, ev1))
     return out
 
 
@@ -318,15 +331,9 @@ def mlp_backward(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, pac
     n_pts = d_out.shape[0]
     scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
     d_flat = torch.empty_like(flat)
-    with torch.cuda.device(d_out.device):
-        if PROFILE is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
+    with torch.cuda.device(d_out.device), _timed("mlp_bwd", n_pts):
         check(lib.nerf_mlp_bwd(n_pts, pts_per_ray, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
                                packed_fwd.data_ptr(), packed_bwd.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(), _stream()))
-        if PROFILE is not None:
-            ev1.record()
-            PROFILE.append(("mlp_bwd", n_pts, ev0, ev1))
     return d_flat
 
 

@@ -459,7 +459,48 @@ def test_train_step_matches_reference(device):
     # the repacked streams must follow the optimiser step
     with torch.no_grad():
         rgb2, _, _, _ = render(H, W, K, chunk=1 << 15, rays=rays, **dict(kw, retraw=False))
-    assert float((rgb2 - rgb).abs().max()) > 0.0
+    assert float((rgb2 - rgb.detach()).abs().max()) > 0.0
+
+
+def test_fern_train_step_matches_oracle(device):
+    """Forward-facing configuration (NDC warp, density noise, 64+64 samples, no white background): loss and every
+    gradient of one step against autograd through the oracle on the same rays and the same random draws."""
+    from nerf_amd.run_nerf import render
+    from nerf_amd.run_nerf_helpers import img2mse
+    g = golden("march")
+    sc, si, perturb, std, white, lindisp, near, far, ndc, H, W, focal = g["fern_train.cfg"]
+    sc, si, H, W = int(sc), int(si), int(H), int(W)
+    assert ndc == 1.0 and std == 1.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    sd_c, sd_f = _peaky(O.random_state_dict(31), 40.0), _peaky(O.random_state_dict(32), 60.0)
+    mc, mf = _model(sd_c, device), _model(sd_f, device)
+    rays = T(g["fern_train.rays"])
+    n = rays.shape[1]
+    target = T(np.random.Generator(np.random.PCG64(3)).uniform(0, 1, size=(n, 3)).astype(np.float32))
+    kw = dict(network_fn=mc, network_query_fn=_query_fn(), N_samples=sc, N_importance=si, network_fine=mf, perturb=perturb,
+              raw_noise_std=std, white_bkgd=bool(white), lindisp=False, retraw=True, use_viewdirs=True, ndc=True,
+              near=near, far=far, pytest=True)
+    rgb, disp, acc, extras = render(H, W, K, chunk=1 << 15, rays=rays.to(device), **kw)
+    loss = img2mse(rgb, target.to(device)) + img2mse(extras["rgb0"], target.to(device))
+    loss.backward()
+
+    pc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+    t_rand, u, nc, nf = _rng_inputs(n, sc, si, perturb, std)
+    packed = O.pack_rays(rays[0], rays[1], near, far, use_viewdirs=True, ndc=(H, W, K[0][0]))
+    want = O.render_chunks(packed, 1 << 15, sd_coarse=pc, sd_fine=pf, n_coarse=sc, n_fine=si, perturb=perturb,
+                           white_bkgd=bool(white), t_rand=t_rand, u=u, noise_coarse=nc, noise_fine=nf, retraw=True)
+    # (bit-for-bit on the machine that made the fixture; another host's thread count changes the GEMM blocking)
+    close(want["rgb_map"], g["fern_train.rgb_map"], 2e-4, 2e-5, "oracle reproduces the reference's fern forward")
+    loss_o = O.mse(want["rgb_map"], target) + O.mse(want["rgb0"], target)
+    loss_o.backward()
+    close(loss, loss_o.detach(), 2e-5, 0, "fern loss")
+    for net, model, ref in (("c", mc, pc), ("f", mf, pf)):
+        for k, p in model.named_parameters():
+            a, b = p.grad.cpu().double().reshape(-1), ref[k].grad.double().reshape(-1)
+            rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert rel <= 2e-2, (net, k, rel)
+            np.testing.assert_allclose(float(a.abs().sum()), float(b.abs().sum()), rtol=3e-3, err_msg=f"|grad| {net}.{k}")
 
 
 # ---------------------------------------------------------------------------------------------
