@@ -6,13 +6,15 @@
 //     (earlier) layer's W^T product straight from registers; the transposed weights stream through
 //     the LDS slab ring.  ReLU masks come from the saved activations; each layer's dY is written
 //     feature-major next to them.                                      Bound: MFMA (9088 per 32 points).
-//  2. k_dw_gemm: dW_l = dY_l * X_l^T, a reduction over points.  Both operands are feature-major rows,
-//     i.e. K(points)-contiguous, so a [rows][32 points] tile goes to LDS with whole-line loads and a
-//     lane reads its MFMA operands as 16-byte vectors.  One workgroup owns a whole (up to 256x256)
-//     weight tile for one of KSPLIT slices of the point range: every operand byte is read from HBM
-//     once (64 FLOP per byte).  Bias gradients are row sums of the dY fragments already in registers.
-//  3. k_reduce_slabs: sums the KSPLIT partial slabs in a fixed order (bitwise reproducible, unlike
-//     float atomics).
+//  2. k_dw_gemm: dW_l = dY_l * X_l^T, a reduction over points.  Both operands live in the blocked
+//     layout (mlp_layout.hpp): a chunk of 32 points is 512 contiguous bytes per group of four rows,
+//     copied as-is into LDS, where a lane's ds_read_b128 yields four rows of one point = the A (or B)
+//     operands of four different 32x32 output tiles.  One workgroup owns a whole (up to 256x256)
+//     weight tile for one slice of the point range: every operand byte is read from HBM once
+//     (64 FLOP per byte).  The slices per task are chosen so that all workgroups of the launch carry
+//     the same load and fit the chip in one round.  Bias gradients are row sums of the dY operands.
+//  3. k_reduce_slabs: sums the partial slabs in a fixed order (bitwise reproducible, unlike float
+//     atomics).
 #include "common.hpp"
 #include "mlp_core.hpp"
 
@@ -25,20 +27,29 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
+// Register tiles <-> blocked layout: `rows` = first row group of the tiles inside this workgroup's tile,
+// lane_off = half * GROUP_FLOATS + 4 * (point in tile); one 16-byte access per register quad.
 template <int NT>
-__device__ __forceinline__ void load_tiles(f32x16 (&M)[8], const float* rows, int64_t ldp, uint32_t lane_off) {
+__device__ __forceinline__ void load_tiles(f32x16 (&M)[8], const float* rows, uint32_t lane_off) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) M[t][r] = (rows + (int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * ldp)[lane_off];
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rows + (8 * t + 2 * i) * GROUP_FLOATS + lane_off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) M[t][4 * i + e] = v[e];
+        }
 }
 
 template <int NT>
-__device__ __forceinline__ void store_tiles(const f32x16 (&A)[8], float* rows, int64_t ldp, uint32_t lane_off) {
+__device__ __forceinline__ void store_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) (rows + (int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * ldp)[lane_off] = A[t][r];
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = {A[t][4 * i], A[t][4 * i + 1], A[t][4 * i + 2], A[t][4 * i + 3]};
+            *reinterpret_cast<f32x4*>(rows + (8 * t + 2 * i) * GROUP_FLOATS + lane_off) = v;
+        }
 }
 
 template <bool VIEWDIRS>
@@ -51,8 +62,12 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int64_t p = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + (lane & 31);
     const bool valid = p < n_pts;
-    const int64_t ldp = padded_points(n_pts);
-    const uint32_t lane_off = (uint32_t)(4 * h * ldp + p);
+    const int pw = wave * 32 + (lane & 31);
+    const uint32_t lane_off = (uint32_t)(h * GROUP_FLOATS + pw * 4);
+    const float* const at = act + (int64_t)blockIdx.x * act_rows(VIEWDIRS ? 1 : 0) * TILE_PTS;   // this workgroup's tiles
+    float* const st_ = scr + (int64_t)blockIdx.x * scr_rows(VIEWDIRS ? 1 : 0) * TILE_PTS;
+    constexpr int SCR_HEAD = scr_head(VIEWDIRS ? 1 : 0), SCR_HEAD2 = SCR_HEAD + 32;
+    auto rows_of = [](auto* tile, int row) { return tile + (row / 4) * GROUP_FLOATS; };
 
     {
         const float* gaux = packed_fwd + (int64_t)fwd_stream_blocks(VIEWDIRS ? 1 : 0) * BLOCK_FLOATS;
@@ -75,13 +90,13 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
         f32x4 g = {0, 0, 0, 0};
         if (valid) g = *reinterpret_cast<const f32x4*>(d_out + p * 4);
         d_sigma = g[3];
-        if (h == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) scr[(int64_t)(SCR_HEAD + c) * ldp + p] = g[c];
-            scr[(int64_t)SCR_HEAD2 * ldp + p] = g[3];
+        if (h == 0) {   // head operands of the weight-gradient GEMM: one row group each, zero padded
+            const f32x4 ga = {g[0], g[1], g[2], 0.0f}, gb = {g[3], 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD) + pw * 4) = ga;
+            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD2) + pw * 4) = gb;
         }
         // views layer: d(hidden) = Wrgb^T d_rgb, masked by the saved post-ReLU activations
-        load_tiles<4>(M, act + (int64_t)ACT_VIEWS * ldp, ldp, lane_off);
+        load_tiles<4>(M, rows_of(at, ACT_VIEWS), lane_off);
         const float* wrgb = aux + AUX_HEAD + 256;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -96,12 +111,12 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
                     A[t][4 * i + e] = M[t][4 * i + e] > 0.0f ? v : 0.0f;
                 }
             }
-        store_tiles<4>(A, scr + (int64_t)SCR_VIEWS * ldp, ldp, lane_off);
+        store_tiles<4>(A, rows_of(st_, SCR_VIEWS), lane_off);
         // d(feature) = Wviews[:, :256]^T dY_views; feature_linear has no activation
         run_section<8, 4, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return A[ti]; });
 #pragma unroll
         for (int t = 0; t < 8; ++t) A[t] = B[t];
-        store_tiles<8>(A, scr + (int64_t)SCR_FEAT * ldp, ldp, lane_off);
+        store_tiles<8>(A, rows_of(st_, SCR_FEAT), lane_off);
         first_layer = 7;
     } else {
         // d(h7) = Wout^T d_out
@@ -109,11 +124,11 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
 #pragma unroll
         for (int c = 0; c < 8; ++c) g[c] = (valid && c < output_ch) ? d_out[p * output_ch + c] : 0.0f;
         if (h == 0) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < output_ch) scr[(int64_t)(SCR_HEAD + c) * ldp + p] = g[c];
+            const f32x4 ga = {g[0], g[1], g[2], g[3]}, gb = {g[4], g[5], g[6], g[7]};
+            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD) + pw * 4) = ga;
+            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD + 4) + pw * 4) = gb;
         }
-        load_tiles<8>(M, act + (int64_t)(ACT_H0 + 7 * 256) * ldp, ldp, lane_off);
+        load_tiles<8>(M, rows_of(at, ACT_H0 + 7 * 256), lane_off);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -122,14 +137,14 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
                 for (int c = 0; c < output_ch; ++c) v = fmaf(aux[AUX_HEAD + c * 256 + t * 32 + h * 16 + r], g[c], v);
                 A[t][r] = M[t][r] > 0.0f ? v : 0.0f;
             }
-        store_tiles<8>(A, scr + (int64_t)(SCR_H0 + 7 * 256) * ldp, ldp, lane_off);
+        store_tiles<8>(A, rows_of(st_, SCR_H0 + 7 * 256), lane_off);
         first_layer = 6;
     }
 
 #pragma unroll 1
     for (int l = first_layer; l >= 0; --l) {
         // saved output of pts layer l (ReLU mask), requested before the matrix work that hides its latency
-        load_tiles<8>(M, act + (int64_t)(ACT_H0 + 256 * l) * ldp, ldp, lane_off);
+        load_tiles<8>(M, rows_of(at, ACT_H0 + 256 * l), lane_off);
         run_section<8, 8, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return A[ti]; });
         if (VIEWDIRS && l == 7) {
             const float* wa = aux + AUX_HEAD;
@@ -146,83 +161,189 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) A[t][r] = M[t][r] > 0.0f ? B[t][r] : 0.0f;
-        store_tiles<8>(A, scr + (int64_t)(SCR_H0 + 256 * l) * ldp, ldp, lane_off);
+        store_tiles<8>(A, rows_of(st_, SCR_H0 + 256 * l), lane_off);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage 2
 // ------------------------------------------------------------------------------------------------
+// One task = one weight matrix (or two that share an operand).  Its operands are up to four runs of
+// consecutive row groups, copied chunk by chunk into consecutive LDS "slots" (one slot = one group =
+// 4 rows x 32 points):  input run 1 | dY run 1 | dY run 2 | input run 2.
 struct DwTask {
-    int cfg;        // tile shape, see k_dw_gemm
-    int a_row;      // first dY row in the workspace
-    int b_row;      // first input row in the saved activations
-    int M, N;       // valid output rows / columns (<= tile)
-    int ldc;        // row stride of the weight matrix in the flat parameter vector
-    int64_t out;    // offset of W[0][first column] in the flat parameter vector
-    int64_t bias;   // offset of the bias vector, or -1
+    int kind;             // see wave_job()
+    int a_grp, a_n;       // dY groups in the workspace: first, count
+    int a2_grp, a2_n;
+    int b_grp, b_n;       // input groups in the saved activations
+    int b2_grp, b2_n;
+    int M, N, N2;         // valid rows of the dY run(s); valid columns of input run 1 / run 2
+    int ldc, ldc2;        // row stride of the weight matrices in the flat parameter vector
+    int first, nsplit;    // workgroups [first, first + nsplit) slice the point range of this task
+    int64_t out, out2;    // W[0][first column] for (dY 1 x input 1) and for the second product
+    int64_t bias;         // bias vector of dY run 1, or -1
 };
 struct DwTasks {
-    DwTask t[16];
+    DwTask t[14];
+    int n;
 };
 
-constexpr int KT = 32;           // points per K chunk
-constexpr int LDT = KT + 4;      // padded LDS row (floats): 16-byte aligned, conflict-free b128 reads
-
+constexpr int KT = 32;              // points per chunk
+constexpr int GS = KT * 4 + 4;      // floats per LDS slot: 32 points x 4 rows, padded so that lanes reading
+                                    // consecutive slots start 4 banks apart (conflict-free b128 / b64 reads)
+constexpr int MAX_SLOTS = 144;      // the encoded-position task: 2 x 64 dY groups + 16 input groups
 constexpr int DW_THREADS = 512;
+constexpr size_t DW_LDS_BYTES = 2 * (size_t)MAX_SLOTS * GS * sizeof(float);
 
-template <int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void dw_body(const DwTask& task, int split, int64_t ldp, const float* __restrict__ act,
-                                        const float* __restrict__ scr_rows, float* __restrict__ slabs,
-                                        int64_t slab_stride, float* smem) {
-    static_assert(64 * WM * WN == DW_THREADS, "every tile shape uses all eight waves");
-    constexpr int NTHREADS = DW_THREADS, TILE_M = WM * TM * 32, TILE_N = WN * TN * 32;
-    constexpr int ROWS = TILE_M + TILE_N;
-    constexpr int LOADS = (ROWS * (KT / 4) + NTHREADS - 1) / NTHREADS;  // float4 per thread per chunk
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
+// What one wave of a task's workgroup computes: a (32*TM) x (32*TN) block of one product.
+struct WaveJob {
+    int mode;         // 0 idle | 1: 128 rows x 64 cols | 2: 128 rows x 32 cols | 3: <=8 rows x 64 cols
+    int a_slot, b_slot;
+    int row0, col0;   // position of the block in the weight matrix
+    int M, N, ldc;
+    int64_t out, bias;
+};
 
-    const int64_t nchunks = ldp / KT;
-    const int64_t per = (nchunks + KSPLIT - 1) / KSPLIT;
+struct RunStarts { int a1, a2, b2; };   // first LDS slot of dY run 1, dY run 2, input run 2 (input run 1 starts at 0)
+__host__ __device__ inline RunStarts run_starts(const DwTask& t) {
+    RunStarts r;
+    r.a1 = (t.b_n + 15) & ~15;
+    r.a2 = r.a1 + ((t.a_n + 15) & ~15);
+    r.b2 = r.a2 + ((t.a2_n + 15) & ~15);
+    return r;
+}
+
+// kind 0  hidden layer, 256 x 256:  waves 2 x 4, each 128 x 64
+// kind 1  encoded-position inputs of layers 0 and 5: dY0 ++ dY5 (512 rows) x 64 inputs: waves 0..3, 128 x 64 each
+// kind 2  views layer: 128 rows x (256 feature ++ 32 direction inputs): waves 0..3 128 x 64, wave 4 128 x 32
+// kind 3  head: <= 8 rows x (64 * b_n / 16) inputs: wave w covers columns 64 w
+__device__ __forceinline__ WaveJob wave_job(const DwTask& t, int w) {
+    const RunStarts rs = run_starts(t);
+    WaveJob j{};
+    j.M = t.M; j.N = t.N; j.ldc = t.ldc; j.out = t.out; j.bias = -1;
+    switch (t.kind) {
+        case 0:
+            j.mode = 1; j.a_slot = rs.a1 + (w >> 2) * 32; j.b_slot = (w & 3) * 16; j.row0 = (w >> 2) * 128; j.col0 = (w & 3) * 64;
+            if ((w & 3) == 0) j.bias = t.bias;
+            break;
+        case 1:
+            if (w < 4) {
+                j.mode = 1; j.a_slot = rs.a1 + w * 32; j.b_slot = 0; j.row0 = (w & 1) * 128; j.col0 = 0;
+                if (w < 2) j.bias = t.bias; else { j.out = t.out2; j.ldc = t.ldc2; }
+            }
+            break;
+        case 2:
+            if (w < 4) {
+                j.mode = 1; j.a_slot = rs.a1; j.b_slot = w * 16; j.row0 = 0; j.col0 = w * 64;
+                if (w == 0) j.bias = t.bias;
+            } else if (w == 4 && t.b2_n > 0) {
+                j.mode = 2; j.a_slot = rs.a1; j.b_slot = rs.b2; j.row0 = 0; j.col0 = 0; j.out = t.out2; j.ldc = t.ldc2; j.N = t.N2;
+            }
+            break;
+        default:
+            if (w * 16 < t.b_n) {
+                j.mode = 3; j.a_slot = rs.a1; j.b_slot = w * 16; j.row0 = 0; j.col0 = w * 64;
+                if (w == 0) j.bias = t.bias;
+            }
+            break;
+    }
+    return j;
+}
+
+// The chunk loop of one wave.  All waves of the workgroup copy chunks (global -> registers -> LDS, two LDS
+// buffers) and meet at one barrier per chunk; TM x TN MFMA tiles per wave depend on the job.
+template <int MODE, int NLOADS>
+__device__ __forceinline__ void dw_loop(const DwTask& task, const WaveJob& job, int split, int64_t nchunks,
+                                        int64_t tile_floats, const float* __restrict__ act,
+                                        const float* __restrict__ scr, float* __restrict__ slab, float* smem) {
+    constexpr int TM = (MODE == 1 || MODE == 2) ? 4 : (MODE == 3 ? 1 : 0);
+    constexpr int TN = (MODE == 1 || MODE == 3) ? 2 : (MODE == 2 ? 1 : 0);
+    constexpr int NACC = TM * TN > 0 ? TM * TN : 1;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l32 = lane & 31;
+
+    const int64_t per = (nchunks + task.nsplit - 1) / task.nsplit;
     const int64_t c0 = split * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
 
-    const float* a_base = scr_rows + (int64_t)task.a_row * ldp;
-    const float* b_base = act + (int64_t)task.b_row * ldp;
-
-    // staging map: float4 i of the [ROWS][KT] chunk -> row i/8, column 4*(i%8); rows < TILE_M come from dY
-    const float* src[LOADS];
-    int dst[LOADS];
+    // ---- staging map.  LDS slots: input run 1 | dY run 1 | dY run 2 | input run 2, each run starting at a
+    // multiple of 16 slots, so that the 16 slots a load instruction k covers (slot 16 k + tid / 32, point tid % 32)
+    // come from one buffer: scalar base per k, one per-lane offset for all k.
+    const RunStarts rs = run_starts(task);
+    const float* gbase[NLOADS];
+    uint32_t lane_src[NLOADS];
+    const int sl = tid >> 5;
 #pragma unroll
-    for (int k = 0; k < LOADS; ++k) {
-        const int i = tid + k * NTHREADS;
-        const int row = i >> 3, c4 = (i & 7) * 4;
-        const bool ok = row < ROWS;
-        const int rr = ok ? row : 0;
-        src[k] = (rr < TILE_M ? a_base + (int64_t)rr * ldp : b_base + (int64_t)(rr - TILE_M) * ldp) + c4;
-        dst[k] = ok ? rr * LDT + c4 : -1;
+    for (int k = 0; k < NLOADS; ++k) {
+        const int s0 = 16 * k;
+        int grp, n;
+        const float* base;
+        if (s0 < rs.a1)      { base = act; grp = task.b_grp + s0;            n = task.b_n - s0; }
+        else if (s0 < rs.a2) { base = scr; grp = task.a_grp + (s0 - rs.a1);  n = task.a_n - (s0 - rs.a1); }
+        else if (s0 < rs.b2) { base = scr; grp = task.a2_grp + (s0 - rs.a2); n = task.a2_n - (s0 - rs.a2); }
+        else                 { base = act; grp = task.b2_grp + (s0 - rs.b2); n = task.b2_n - (s0 - rs.b2); }
+        gbase[k] = base + (int64_t)grp * GROUP_FLOATS;
+        // slots past the end of a run are filled with a copy of the run's first group: no lane is ever masked,
+        // the loop body has no branches, and nothing reads those slots
+        const int nvalid = n > 16 ? 16 : n;
+        lane_src[k] = (uint32_t)((sl < nvalid ? sl : 0) * GROUP_FLOATS + l32 * 4);
     }
+    const int dst0 = sl * GS + l32 * 4;
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float bsum[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) bsum[i] = 0.0f;
-
-    f32x4 stage[LOADS];
+    f32x4 stage[NLOADS];
     auto issue = [&](int64_t chunk) {
+        const int64_t off = (chunk >> 2) * tile_floats + (chunk & 3) * (KT * 4);   // both buffers share the tile stride
 #pragma unroll
-        for (int k = 0; k < LOADS; ++k) stage[k] = *reinterpret_cast<const f32x4*>(src[k] + chunk * KT);
+        for (int k = 0; k < NLOADS; ++k) stage[k] = *reinterpret_cast<const f32x4*>(gbase[k] + off + lane_src[k]);
     };
     auto commit = [&](int buf) {
-        float* base = smem + buf * (ROWS * LDT);
+        float* base = smem + buf * (MAX_SLOTS * GS) + dst0;
 #pragma unroll
-        for (int k = 0; k < LOADS; ++k)
-            if (dst[k] >= 0) *reinterpret_cast<f32x4*>(base + dst[k]) = stage[k];
+        for (int k = 0; k < NLOADS; ++k) *reinterpret_cast<f32x4*>(base + 16 * k * GS) = stage[k];
+    };
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool want_bias = job.bias >= 0;
+
+    // this lane's operand addresses inside a buffer (floats); step s adds 8 s (two points per step, lane half = parity)
+    int a_off = 0, b_off = 0;
+    bool a_live = true;
+    if constexpr (MODE == 1 || MODE == 2) a_off = (job.a_slot + l32) * GS + 4 * h;
+    if constexpr (MODE == 3) { a_off = (job.a_slot + (l32 >> 2)) * GS + (l32 & 3) + 4 * h; a_live = l32 < job.M; }
+    if constexpr (MODE == 1 || MODE == 3) b_off = (job.b_slot + (l32 >> 1)) * GS + 2 * (l32 & 1) + 4 * h;
+    if constexpr (MODE == 2) b_off = (job.b_slot + (l32 >> 2)) * GS + (l32 & 3) + 4 * h;
+    if (!a_live) a_off = 0;
+
+    auto compute = [&](const float* buf, int s_begin, int s_end, float (&csum)[4]) {
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int s = s_begin; s < s_end; ++s) {
+                float a[4], b[2];
+                if constexpr (TM == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(buf + a_off + 8 * s);
+                    a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+                } else {
+                    const float v = buf[a_off + 8 * s];
+                    a[0] = a_live ? v : 0.0f;
+                }
+                if constexpr (TN == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(buf + b_off + 8 * s);
+                    b[0] = v.x; b[1] = v.y;
+                } else {
+                    b[0] = buf[b_off + 8 * s];
+                }
+#pragma unroll
+                for (int e = 0; e < TM; ++e) csum[e] += a[e];
+#pragma unroll
+                for (int e = 0; e < TM; ++e)
+#pragma unroll
+                    for (int f = 0; f < TN; ++f)
+                        acc[e * TN + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[f], acc[e * TN + f], 0, 0, 0);
+            }
+        }
     };
 
     if (c0 < c1) {
@@ -232,89 +353,103 @@ __device__ __forceinline__ void dw_body(const DwTask& task, int split, int64_t l
     __syncthreads();
     for (int64_t c = c0; c < c1; ++c) {
         const int buf = (int)((c - c0) & 1);
-        if (c + 1 < c1) issue(c + 1);  // in flight under this chunk's MFMAs
-        const float* At = smem + buf * (ROWS * LDT) + (wm * TM * 32 + l32) * LDT + 4 * h;
-        const float* Bt = smem + buf * (ROWS * LDT) + (TILE_M + wn * TN * 32 + l32) * LDT + 4 * h;
+        const float* cur = smem + buf * (MAX_SLOTS * GS);
+        float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        issue(c + 1 < c1 ? c + 1 : c);          // in flight under the first half of this chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink the loads to just above their stores)
+        compute(cur, 0, KT / 4, csum);          // (the last iteration re-stages its own chunk: no branch in the body)
+        __builtin_amdgcn_sched_barrier(0);
+        commit(buf ^ 1);                        // the other buffer was last read before the previous barrier
+        compute(cur, KT / 4, KT / 2, csum);
+        if (want_bias) {
 #pragma unroll
-        for (int q = 0; q < KT / 8; ++q) {
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(At + i * 32 * LDT + 8 * q);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bt + j * 32 * LDT + 8 * q);
-            if (wn == 0) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) bsum[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) bsum[e] += csum[e];
         }
-        if (c + 1 < c1) commit(buf ^ 1);
         __syncthreads();
     }
 
-    float* out = slabs + (int64_t)split * slab_stride;
+    if constexpr (MODE != 0) {
+        float* out = slab + job.out;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int e = 0; e < TM; ++e)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = (wn * TN + j) * 32 + l32;
+            for (int f = 0; f < TN; ++f) {
+                const int col = job.col0 + (TN == 2 ? 2 * l32 + f : l32);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < task.M && n < task.N) out[task.out + (int64_t)m * task.ldc + n] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int row = job.row0 + (TM == 4 ? 4 * m + e : m);
+                    if (row < job.M && col < job.N) out[(int64_t)row * job.ldc + col] = acc[e * TN + f][r];
+                }
+            }
+        if (want_bias) {
+#pragma unroll
+            for (int e = 0; e < TM; ++e) {
+                const float s = bsum[e] + __shfl_xor(bsum[e], 32, 64);
+                const int row = job.row0 + (TM == 4 ? 4 * l32 + e : l32);
+                if (h == 0 && row < job.M) slab[job.bias + row] = s;
             }
         }
-    if (task.bias >= 0 && wn == 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-            const int m = (wm * TM + i) * 32 + l32;
-            if (h == 0 && m < task.M) out[task.bias + m] = s;
-        }
     }
+}
+
+__global__ void __launch_bounds__(DW_THREADS)
+k_dw_gemm(DwTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __restrict__ act,
+          const float* __restrict__ scr, float* __restrict__ slabs, int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int ti = 0;
+    for (int i = 1; i < tasks.n; ++i)
+        if ((int)blockIdx.x >= tasks.t[i].first) ti = i;
+    const DwTask task = tasks.t[ti];
+    const int split = (int)blockIdx.x - task.first;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const WaveJob job = wave_job(task, wave);
+    float* slab = slabs + (int64_t)split * slab_stride;
+    // (wave job, 16-slot groups per chunk of the task's kind)
+#define DW_GO(MODE, NLOADS) dw_loop<MODE, NLOADS>(task, job, split, nchunks, tile_floats, act, scr, slab, smem)
+    switch (task.kind) {
+        case 0: DW_GO(1, 8); break;
+        case 1: if (job.mode == 1) DW_GO(1, 9); else DW_GO(0, 9); break;
+        case 2: if (job.mode == 1) DW_GO(1, 7); else if (job.mode == 2) DW_GO(2, 7); else DW_GO(0, 7); break;
+        default: if (job.mode == 3) DW_GO(3, 5); else DW_GO(0, 5); break;
+    }
+#undef DW_GO
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage 3
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ slabs, int64_t slab_stride, int64_t n,
-                                                      float* __restrict__ d_params) {
+                                                      int nslabs, float* __restrict__ d_params) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < KSPLIT; ++k) s += slabs[k * slab_stride + i];
+        for (int k = 0; k < nslabs; ++k) s += slabs[k * slab_stride + i];
         d_params[i] = s;
     }
 }
 
-// Tile shapes (rows of dY x rows of X per workgroup, eight waves each):
-//   0: 256x256  hidden layers, feature_linear      1: 256x64  encoded-position inputs of layers 0 and 5
-//   2: 128x256  views layer, feature inputs        3: 128x64  views layer, encoded directions (27 used)
-//   4:  64x128  rgb head (3 rows used)             5:  32x256 alpha / output_linear head
-// All tasks of a backward run in ONE launch, largest first, so the short ones fill the tail of the long ones.
-__global__ void __launch_bounds__(DW_THREADS)
-k_dw_gemm(DwTasks tasks, int64_t ldp, const float* __restrict__ act, const float* __restrict__ scr_rows,
-          float* __restrict__ slabs, int64_t slab_stride) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DwTask task = tasks.t[blockIdx.x / KSPLIT];
-    const int split = blockIdx.x % KSPLIT;
-    switch (task.cfg) {
-        case 0: dw_body<2, 4, 4, 2>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
-        case 1: dw_body<8, 1, 1, 2>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
-        case 2: dw_body<2, 4, 2, 2>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
-        case 3: dw_body<4, 2, 1, 1>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
-        case 4: dw_body<2, 4, 1, 1>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
-        default: dw_body<1, 8, 1, 1>(task, split, ldp, act, scr_rows, slabs, slab_stride, smem); break;
+// Slices per task: repeatedly give one more slice to the task whose slices are longest, until the launch
+// has one workgroup per compute unit.  cost = time of one chunk of the task relative to the others
+// (MFMA issue per SIMD, or the operand copy where that is longer).
+void assign_splits(DwTasks& tk, const int* cost, int64_t nchunks, int n_wg) {
+    int used = 0;
+    for (int i = 0; i < tk.n; ++i) { tk.t[i].nsplit = 1; ++used; }
+    const int cap = (int)(nchunks < KSPLIT ? (nchunks > 0 ? nchunks : 1) : KSPLIT);
+    while (used < n_wg) {
+        int best = -1;
+        double worst = 0.0;
+        for (int i = 0; i < tk.n; ++i) {
+            if (tk.t[i].nsplit >= cap) continue;
+            const double per = (double)cost[i] / tk.t[i].nsplit;
+            if (per > worst) { worst = per; best = i; }
+        }
+        if (best < 0) break;
+        ++tk.t[best].nsplit;
+        ++used;
     }
+    int first = 0;
+    for (int i = 0; i < tk.n; ++i) { tk.t[i].first = first; first += tk.t[i].nsplit; }
 }
-
-constexpr size_t DW_LDS_BYTES = 2 * (size_t)512 * LDT * sizeof(float);  // the 256x256 shape: 512 rows, two buffers
 
 }  // namespace
 
@@ -339,18 +474,14 @@ int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float
                    reinterpret_cast<uintptr_t>(packed_fwd) | reinterpret_cast<uintptr_t>(packed_bwd)) & 15) == 0,
                  "nerf_mlp_bwd: buffers must be 16-byte aligned");
     const int64_t ldp = padded_points(n_pts);
-    NERF_REQUIRE(ldp * 4 * 5 < (int64_t)0xffffffff, "nerf_mlp_bwd: n_pts=%lld too large for one call", (long long)n_pts);
     const int64_t blocks = ldp / TILE_PTS;
+    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_bwd: n_pts=%lld too large for one call", (long long)n_pts);
     const int64_t slab = slab_floats(use_viewdirs, output_ch);
-    float* slabs = scratch + (int64_t)SCR_ROWS * ldp;
-
-    // head rows beyond the output channels are zero operands of the head GEMMs; uncovered slab entries
-    // (parameters that receive no gradient) must read as zero in the reduction
-    hipError_t e = hipMemsetAsync(scratch + (int64_t)SCR_HEAD * ldp, 0, 64 * ldp * sizeof(float), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(slabs, 0, (size_t)KSPLIT * slab * sizeof(float), stream);
-    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
+    float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
+    const int SCR_HEAD = scr_head(use_viewdirs), SCR_HEAD2 = SCR_HEAD + 32;
 
     const size_t lds = (RING_FLOATS + AUX_FLOATS) * sizeof(float);
+    hipError_t e;
     if (use_viewdirs) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
@@ -367,31 +498,65 @@ int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float
 
     // ---- dW = dY X^T: one launch over all layers
     DwTasks tk{};
+    int cost[14];
     int nt = 0;
-    for (int l = 1; l < 8; ++l) {
-        const int ldc = (l == 5) ? W + IN_PTS : W;
-        tk.t[nt++] = DwTask{0, SCR_H0 + 256 * l, ACT_H0 + 256 * (l - 1), 256, 256, ldc, po.pts_w[l] + (l == 5 ? IN_PTS : 0), po.pts_b[l]};
+    auto big = [&](int a_row, int b_row, int ldc, int64_t out, int64_t bias) {
+        DwTask t{};
+        t.kind = 0; t.a_grp = a_row / 4; t.a_n = 64; t.b_grp = b_row / 4; t.b_n = 64; t.M = 256; t.N = 256; t.ldc = ldc;
+        t.out = out; t.bias = bias;
+        cost[nt] = 16; tk.t[nt++] = t;
+    };
+    for (int l = 1; l < 8; ++l)
+        big(SCR_H0 + 256 * l, ACT_H0 + 256 * (l - 1), (l == 5) ? W + IN_PTS : W, po.pts_w[l] + (l == 5 ? IN_PTS : 0), po.pts_b[l]);
+    if (use_viewdirs) big(SCR_FEAT, ACT_H0 + 256 * 7, W, po.feat_w, po.feat_b);
+    {   // encoded positions feed layers 0 and 5
+        DwTask t{};
+        t.kind = 1; t.a_grp = SCR_H0 / 4; t.a_n = 64; t.a2_grp = (SCR_H0 + 256 * 5) / 4; t.a2_n = 64; t.b_grp = ACT_ENC_PTS / 4; t.b_n = 16;
+        t.M = 256; t.N = IN_PTS; t.ldc = IN_PTS; t.ldc2 = W + IN_PTS; t.out = po.pts_w[0]; t.out2 = po.pts_w[5]; t.bias = po.pts_b[0];
+        cost[nt] = 9; tk.t[nt++] = t;
     }
     if (use_viewdirs) {
-        tk.t[nt++] = DwTask{0, SCR_FEAT, ACT_H0 + 256 * 7, 256, 256, W, po.feat_w, po.feat_b};
-        tk.t[nt++] = DwTask{2, SCR_VIEWS, ACT_FEAT, 128, 256, po.views_in, po.views_w, po.views_b};
-    }
-    tk.t[nt++] = DwTask{1, SCR_H0, ACT_ENC_PTS, 256, IN_PTS, IN_PTS, po.pts_w[0], po.pts_b[0]};
-    tk.t[nt++] = DwTask{1, SCR_H0 + 256 * 5, ACT_ENC_PTS, 256, IN_PTS, W + IN_PTS, po.pts_w[5], -1};
-    if (use_viewdirs) {
-        tk.t[nt++] = DwTask{5, SCR_HEAD2, ACT_H0 + 256 * 7, 1, 256, W, po.alpha_w, po.alpha_b};
-        tk.t[nt++] = DwTask{3, SCR_VIEWS, ACT_ENC_DIRS, 128, IN_DIRS, po.views_in, po.views_w + W, -1};
-        tk.t[nt++] = DwTask{4, SCR_HEAD, ACT_VIEWS, 3, 128, W / 2, po.rgb_w, po.rgb_b};
+        DwTask t{};
+        t.kind = 2; t.a_grp = SCR_VIEWS / 4; t.a_n = 32; t.b_grp = ACT_FEAT / 4; t.b_n = 64; t.b2_grp = ACT_ENC_DIRS / 4; t.b2_n = 8;
+        t.M = 128; t.N = 256; t.N2 = IN_DIRS; t.ldc = t.ldc2 = po.views_in; t.out = po.views_w; t.out2 = po.views_w + W; t.bias = po.views_b;
+        cost[nt] = 12; tk.t[nt++] = t;
+        DwTask a{};   // alpha: dL/d(sigma) x h7
+        a.kind = 3; a.a_grp = SCR_HEAD2 / 4; a.a_n = 2; a.b_grp = (ACT_H0 + 256 * 7) / 4; a.b_n = 64; a.M = 1; a.N = 256; a.ldc = W;
+        a.out = po.alpha_w; a.bias = po.alpha_b;
+        cost[nt] = 5; tk.t[nt++] = a;
+        DwTask c{};   // rgb: dL/d(rgb) x views hidden
+        c.kind = 3; c.a_grp = SCR_HEAD / 4; c.a_n = 2; c.b_grp = ACT_VIEWS / 4; c.b_n = 32; c.M = 3; c.N = 128; c.ldc = W / 2;
+        c.out = po.rgb_w; c.bias = po.rgb_b;
+        cost[nt] = 3; tk.t[nt++] = c;
     } else {
-        tk.t[nt++] = DwTask{5, SCR_HEAD, ACT_H0 + 256 * 7, output_ch, 256, W, po.out_w, po.out_b};
+        DwTask a{};   // output_linear: dL/d(out) x h7
+        a.kind = 3; a.a_grp = SCR_HEAD / 4; a.a_n = 2; a.b_grp = (ACT_H0 + 256 * 7) / 4; a.b_n = 64; a.M = output_ch; a.N = 256; a.ldc = W;
+        a.out = po.out_w; a.bias = po.out_b;
+        cost[nt] = 5; tk.t[nt++] = a;
     }
+    tk.n = nt;
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu < nt) n_cu = nt;
+    const int64_t nchunks = ldp / KT;
+    assign_splits(tk, cost, nchunks, n_cu);
+    int n_wg = 0, nslabs = 0;
+    for (int i = 0; i < nt; ++i) {
+        n_wg += tk.t[i].nsplit;
+        if (tk.t[i].nsplit > nslabs) nslabs = tk.t[i].nsplit;
+    }
+
+    // slab entries no task covers (parameters that receive no gradient) must read as zero in the reduction
+    e = hipMemsetAsync(slabs, 0, (size_t)nslabs * slab * sizeof(float), stream);
+    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_LDS_BYTES);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_dw_gemm, dim3(nt * KSPLIT), dim3(DW_THREADS), DW_LDS_BYTES, stream, tk, ldp, act, scratch, slabs, slab);
+    hipLaunchKernelGGL(k_dw_gemm, dim3(n_wg), dim3(DW_THREADS), DW_LDS_BYTES, stream, tk, nchunks,
+                       (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab);
     rc = launched("nerf_mlp_bwd (dW)");
     if (rc) return rc;
 
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(1024), dim3(256), 0, stream, slabs, slab, po.total, d_params);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(1024), dim3(256), 0, stream, slabs, slab, po.total, nslabs, d_params);
     return launched("nerf_mlp_bwd (reduce)");
 }
 

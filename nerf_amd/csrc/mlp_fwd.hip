@@ -42,16 +42,17 @@ __device__ __forceinline__ void epilogue(f32x16 (&A)[8], const f32x16 (&B)[8], c
     }
 }
 
-// Save NT activation tiles as feature-major rows.  `rows` is wave-uniform (scalar base), `lane_off` the
-// per-lane element offset 4*half*ldp + point, so each store is scalar base + 32-bit vector offset.
+// Save NT activation tiles into the blocked layout (mlp_layout.hpp).  `rows` points at the tiles' first row
+// group inside this workgroup's tile (wave-uniform), `lane_off` = half * GROUP_FLOATS + 4 * (point in tile):
+// registers 4i..4i+3 of a tile are rows 8i + 4*half + 0..3, i.e. one row group = one 16-byte store.
 template <int NT>
-__device__ __forceinline__ void save_tiles(const f32x16 (&A)[8], float* rows, int64_t ldp, uint32_t lane_off, float msk) {
+__device__ __forceinline__ void save_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off, float msk) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float* row = rows + (int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * ldp;
-            row[lane_off] = A[t][r] * msk;
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = {A[t][4 * i] * msk, A[t][4 * i + 1] * msk, A[t][4 * i + 2] * msk, A[t][4 * i + 3] * msk};
+            *reinterpret_cast<f32x4*>(rows + (8 * t + 2 * i) * GROUP_FLOATS + lane_off) = v;
         }
 }
 
@@ -89,8 +90,10 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
     const int64_t p = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + (lane & 31);
     const bool valid = p < n_pts;
     const int64_t pl = valid ? p : n_pts - 1;
-    const int64_t ldp = padded_points(n_pts);
     constexpr bool save = SAVE;
+    // this workgroup's tile of the saved activations, and this lane's point inside it
+    float* const tile = save ? act + (int64_t)blockIdx.x * act_rows(VIEWDIRS ? 1 : 0) * TILE_PTS : nullptr;
+    const int pw = wave * 32 + (lane & 31);
 
     // aux tables -> LDS (plain loads, before the ring starts)
     const int stream_blocks = fwd_stream_blocks(VIEWDIRS ? 1 : 0);
@@ -158,7 +161,7 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
                 const int f0 = enc_pts_feature(s, 0), f1 = enc_pts_feature(s, 1);
                 const int f = h ? (f1 < 0 ? 63 : f1) : f0;
                 const float v = (valid && !(h && f1 < 0)) ? (s < 16 ? E[0][s] : E[1][s - 16]) : 0.0f;
-                act[(int64_t)(ACT_ENC_PTS + f) * ldp + p] = v;
+                tile[((ACT_ENC_PTS + f) >> 2) * GROUP_FLOATS + pw * 4 + (f & 3)] = v;
             }
             if (VIEWDIRS) {
 #pragma unroll
@@ -168,7 +171,7 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
                     const int g1 = s == 1 ? 29 : (s == 14 ? 30 : (s == 15 ? 31 : f1));
                     const int f = h ? g1 : f0;
                     const bool real = h ? (f1 >= 0) : (s < 14);
-                    act[(int64_t)(ACT_ENC_DIRS + f) * ldp + p] = (valid && real) ? D[s] : 0.0f;
+                    tile[((ACT_ENC_DIRS + f) >> 2) * GROUP_FLOATS + pw * 4 + (f & 3)] = (valid && real) ? D[s] : 0.0f;
                 }
             }
         }
@@ -185,12 +188,12 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
 
     f32x16 A[8], B[8];
     const float msk = valid ? 1.0f : 0.0f;  // padding columns of the saved activations must be zero
-    const uint32_t lane_off = (uint32_t)(4 * h * ldp + p);
+    const uint32_t lane_off = (uint32_t)(h * GROUP_FLOATS + pw * 4);
 
     // layer 0: encoded position -> B
     run_section<8, 2, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return E[ti]; });
     epilogue<8, true>(A, B, aux + AUX_BIAS, h);
-    if constexpr (save) save_tiles<8>(A, act + (int64_t)ACT_H0 * ldp, ldp, lane_off, msk);
+    if constexpr (save) save_tiles<8>(A, tile + (ACT_H0 / 4) * GROUP_FLOATS, lane_off, msk);
 
     float sigma = 0.0f;
     const int n_hidden = VIEWDIRS ? 9 : 8;  // layers 1..7, then feature_linear as "layer 8"
@@ -201,14 +204,14 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
         const float* bias = aux + AUX_BIAS + l * 256;
         if (l < 8) epilogue<8, true>(A, B, bias, h);
         else epilogue<8, false>(A, B, bias, h);
-        if constexpr (save) save_tiles<8>(A, act + (int64_t)(ACT_H0 + 256 * l) * ldp, ldp, lane_off, msk);  // l == 8: ACT_FEAT
+        if constexpr (save) save_tiles<8>(A, tile + ((ACT_H0 + 256 * l) / 4) * GROUP_FLOATS, lane_off, msk);  // l == 8: ACT_FEAT
         if (VIEWDIRS && l == 7) sigma = head_dot<8>(A, aux + AUX_HEAD, h) + aux[AUX_HEAD + 256 + 384];
     }
 
     if (VIEWDIRS) {
         run_section<4, 9, false>(st, lane, B, [&]<int ti>() -> const f32x16& { if constexpr (ti < 8) return A[ti]; else return D; });
         epilogue<4, true>(A, B, aux + AUX_BIAS + 9 * 256, h);
-        if constexpr (save) save_tiles<4>(A, act + (int64_t)ACT_VIEWS * ldp, ldp, lane_off, msk);
+        if constexpr (save) save_tiles<4>(A, tile + (ACT_VIEWS / 4) * GROUP_FLOATS, lane_off, msk);
         const float* wrgb = aux + AUX_HEAD + 256;
         const float* hb = aux + AUX_HEAD + 256 + 384;
         const float r = head_dot<4>(A, wrgb, h) + hb[1];
@@ -323,7 +326,7 @@ int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* 
                  "nerf_mlp_fwd: packed_fwd and out must be 16-byte aligned");
     const int64_t blocks = (n_pts + TILE_PTS - 1) / TILE_PTS;
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd: n_pts=%lld too large for one launch", (long long)n_pts);
-    NERF_REQUIRE(!act || padded_points(n_pts) * 4 * 5 < (int64_t)0xffffffff, "nerf_mlp_fwd: n_pts=%lld too large to save activations in one call", (long long)n_pts);
+    NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd: act must be 16-byte aligned");
     auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)FWD_LDS_BYTES);
@@ -346,7 +349,7 @@ int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int ou
                  "nerf_mlp_fwd_encoded: packed_fwd and out must be 16-byte aligned");
     const int64_t blocks = (n_pts + TILE_PTS - 1) / TILE_PTS;
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_encoded: n_pts=%lld too large for one launch", (long long)n_pts);
-    NERF_REQUIRE(!act || padded_points(n_pts) * 4 * 5 < (int64_t)0xffffffff, "nerf_mlp_fwd_encoded: n_pts=%lld too large to save activations in one call", (long long)n_pts);
+    NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd_encoded: act must be 16-byte aligned");
     const int ldx = IN_PTS + (use_viewdirs ? IN_DIRS : 0);
     auto go = [&](auto kernel, int och) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -216,33 +216,48 @@ NL_HD inline int64_t bwd_source(int use_viewdirs, int output_ch, int64_t idx) {
 }
 
 // ---- saved activations (training) --------------------------------------------------------------
-// Feature-major rows of `ldp` floats (ldp = n_pts rounded up to TILE_PTS; padding columns are zero):
+// Blocked by forward workgroup: tile T = points [128 T, 128 T + 128) holds all rows of those points, and
+// within a tile rows are grouped by four:
+//     float (row, point p)  at  ((T * rows/4 + row/4) * 128 + p % 128) * 4 + row % 4.
+// Four consecutive accumulator registers of a lane are four consecutive feature rows of its point, so
+// the MLP kernels save and reload activations as one 16-byte access per register quad, a wavefront's
+// access covers 512 contiguous bytes per lane half, and a workgroup's whole tile is one contiguous
+// region.  The weight-gradient GEMM stages [group][32 points][4 rows] chunks, 512 contiguous bytes per
+// group, and reads a lane's four rows with one ds_read_b128.  n_pts is rounded up to whole tiles;
+// padding points hold zeros.  Rows:
 //   rows   0.. 63  encoded positions (row 63 zero)        rows 64.. 95  encoded directions (27 used)
 //   rows  96+256*l .. +255  output of pts layer l after ReLU (l = 0..7)
 //   rows 2144..2399 feature_linear output                  rows 2400..2527 views layer output after ReLU
 constexpr int ACT_ENC_PTS = 0, ACT_ENC_DIRS = 64, ACT_H0 = 96, ACT_FEAT = 96 + 8 * 256, ACT_VIEWS = ACT_FEAT + 256;
 constexpr int ACT_ROWS = ACT_VIEWS + 128;
+constexpr int GROUP_FLOATS = TILE_PTS * 4;   // one group: 4 rows x 128 points
+NL_HD constexpr int act_rows(int use_viewdirs) { return use_viewdirs ? ACT_ROWS : ACT_FEAT; }
 NL_HD inline int64_t padded_points(int64_t n_pts) { return (n_pts + TILE_PTS - 1) / TILE_PTS * TILE_PTS; }
 NL_HD inline int64_t act_floats(int use_viewdirs, int64_t n_pts) {
-    return (int64_t)(use_viewdirs ? ACT_ROWS : ACT_FEAT) * padded_points(n_pts);
+    return (int64_t)act_rows(use_viewdirs) * padded_points(n_pts);
+}
+NL_HD inline int64_t blocked_index(int rows_per_tile, int row, int64_t p) {
+    return ((p / TILE_PTS) * (rows_per_tile / 4) + row / 4) * GROUP_FLOATS + (p % TILE_PTS) * 4 + row % 4;
 }
 
 // ---- backward workspace --------------------------------------------------------------------------
-// Rows of `ldp` floats holding dL/d(pre-activation) of every layer, in the layout of the activations:
-//   rows 0..2047 pts layers 0..7 | 2048..2303 feature_linear | 2304..2431 views layer |
-//   2432..2463 head rows A: dL/d(rgb) (view branch) or dL/d(out channel c), the rest zero
-//   2464..2495 head rows B: dL/d(sigma) in the first row (view branch), the rest zero.
+// dL/d(pre-activation) of every layer in the blocked layout of the activations, with the same number of
+// rows per tile as the activations (one tile stride serves both operands of the weight-gradient GEMM):
+//   rows 0..2047 pts layers 0..7 | (view branch) 2048..2303 feature_linear | 2304..2431 views layer |
+//   head rows A (8 rows at scr_head): dL/d(rgb) and a zero, or dL/d(out channel c) zero padded to 8
+//   head rows B (4 rows at scr_head + 32, view branch): dL/d(sigma) and three zeros.
 // Then KSPLIT slabs of partial parameter gradients (one per slice of the point range), each
 // `slab_floats` long, summed in slab order by the final reduction.
-constexpr int SCR_H0 = 0, SCR_FEAT = 8 * 256, SCR_VIEWS = SCR_FEAT + 256, SCR_HEAD = SCR_VIEWS + 128;
-constexpr int SCR_HEAD2 = SCR_HEAD + 32;
-constexpr int SCR_ROWS = SCR_HEAD2 + 32;
-constexpr int KSPLIT = 32;
+constexpr int SCR_H0 = 0, SCR_FEAT = 8 * 256, SCR_VIEWS = SCR_FEAT + 256;
+NL_HD constexpr int scr_head(int use_viewdirs) { return use_viewdirs ? SCR_VIEWS + 128 : 8 * 256; }
+NL_HD constexpr int scr_rows(int use_viewdirs) { return act_rows(use_viewdirs); }
+static_assert(SCR_VIEWS + 128 + 64 <= ACT_ROWS && 8 * 256 + 64 <= ACT_FEAT, "head rows fit below the activations' row count");
+constexpr int KSPLIT = 32;               // upper bound of point-range slices per weight tile
 NL_HD inline int64_t slab_floats(int use_viewdirs, int output_ch) {
     return (param_offsets(use_viewdirs, output_ch).total + 63) / 64 * 64;
 }
 NL_HD inline int64_t scratch_floats(int use_viewdirs, int output_ch, int64_t n_pts) {
-    return (int64_t)SCR_ROWS * padded_points(n_pts) + (int64_t)KSPLIT * slab_floats(use_viewdirs, output_ch);
+    return (int64_t)scr_rows(use_viewdirs) * padded_points(n_pts) + (int64_t)KSPLIT * slab_floats(use_viewdirs, output_ch);
 }
 
 }  // namespace nerflayout
