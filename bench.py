@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 FLOP_PER_POINT_FWD = 1186816          # 2 * 593,408 MAC: one NeRF.forward on one sample point
 FLOP_PER_POINT_TRAIN = 3489024        # forward + dW + dX
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X v_mfma_f32_32x32x2_f32 peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
+# HBM bytes per point of the inference kernel from rocprofv3 PMC passes (profiles/r1_pmc_mlp_fwd.txt):
+# (2 x FETCH_SIZE + WRITE_SIZE) / points = (2 x 36,126 KiB + 64,000 KiB) / 4,096,000 points per launch.
+# The algorithmic figure is 28 B/point (12 B position in, 16 B raw out) + 12 B per ray of view direction.
+PMC_HBM_BYTES_PER_POINT = 34.06
 
 
 def lego_camera(H, W):
@@ -256,7 +260,9 @@ def main():
     achieved = pts * FLOP_PER_POINT_FWD / secs / 1e12 if secs > 0 else 0.0
     roofline = {"bound": "mfma", "kernel": "k_mlp_fwd<viewdirs, inference> (fp32 MFMA 32x32x2)", "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
-                "traffic": None, "launches": len(mlp), "mean_launch_ms": round(1e3 * secs / max(1, len(mlp)), 3),
+                "traffic": round(PMC_HBM_BYTES_PER_POINT * pts / max(1, len(mlp))),
+                "traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of a separate rocprofv3 run, see profiles/",
+                "launches": len(mlp), "mean_launch_ms": round(1e3 * secs / max(1, len(mlp)), 3),
                 "flop_per_point": FLOP_PER_POINT_FWD, "mlp_share_of_step": round(secs / dt, 4)}
 
     out = {"metric": "rays/sec per GPU (train step + render) at 64+128 samples; 1/2/4/8 GPU scaling",

@@ -45,13 +45,15 @@ __device__ __forceinline__ void epilogue(f32x16 (&A)[8], const f32x16 (&B)[8], c
 // Save NT activation tiles into the blocked layout (mlp_layout.hpp).  `rows` points at the tiles' first row
 // group inside this workgroup's tile (wave-uniform), `lane_off` = half * GROUP_FLOATS + 4 * (point in tile):
 // registers 4i..4i+3 of a tile are rows 8i + 4*half + 0..3, i.e. one row group = one 16-byte store.
+// Padding points of the last tile carry the activations of the last real point: finite values that the
+// backward multiplies by exactly-zero gradients.
 template <int NT>
-__device__ __forceinline__ void save_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off, float msk) {
+__device__ __forceinline__ void save_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x4 v = {A[t][4 * i] * msk, A[t][4 * i + 1] * msk, A[t][4 * i + 2] * msk, A[t][4 * i + 3] * msk};
+            const f32x4 v = {A[t][4 * i], A[t][4 * i + 1], A[t][4 * i + 2], A[t][4 * i + 3]};
             *reinterpret_cast<f32x4*>(rows + (8 * t + 2 * i) * GROUP_FLOATS + lane_off) = v;
         }
 }
@@ -187,13 +189,12 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
     st.fetch(0);
 
     f32x16 A[8], B[8];
-    const float msk = valid ? 1.0f : 0.0f;  // padding columns of the saved activations must be zero
     const uint32_t lane_off = (uint32_t)(h * GROUP_FLOATS + pw * 4);
 
     // layer 0: encoded position -> B
     run_section<8, 2, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return E[ti]; });
     epilogue<8, true>(A, B, aux + AUX_BIAS, h);
-    if constexpr (save) save_tiles<8>(A, tile + (ACT_H0 / 4) * GROUP_FLOATS, lane_off, msk);
+    if constexpr (save) save_tiles<8>(A, tile + (ACT_H0 / 4) * GROUP_FLOATS, lane_off);
 
     float sigma = 0.0f;
     const int n_hidden = VIEWDIRS ? 9 : 8;  // layers 1..7, then feature_linear as "layer 8"
@@ -204,14 +205,14 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
         const float* bias = aux + AUX_BIAS + l * 256;
         if (l < 8) epilogue<8, true>(A, B, bias, h);
         else epilogue<8, false>(A, B, bias, h);
-        if constexpr (save) save_tiles<8>(A, tile + ((ACT_H0 + 256 * l) / 4) * GROUP_FLOATS, lane_off, msk);  // l == 8: ACT_FEAT
+        if constexpr (save) save_tiles<8>(A, tile + ((ACT_H0 + 256 * l) / 4) * GROUP_FLOATS, lane_off);  // l == 8: ACT_FEAT
         if (VIEWDIRS && l == 7) sigma = head_dot<8>(A, aux + AUX_HEAD, h) + aux[AUX_HEAD + 256 + 384];
     }
 
     if (VIEWDIRS) {
         run_section<4, 9, false>(st, lane, B, [&]<int ti>() -> const f32x16& { if constexpr (ti < 8) return A[ti]; else return D; });
         epilogue<4, true>(A, B, aux + AUX_BIAS + 9 * 256, h);
-        if constexpr (save) save_tiles<4>(A, tile + (ACT_VIEWS / 4) * GROUP_FLOATS, lane_off, msk);
+        if constexpr (save) save_tiles<4>(A, tile + (ACT_VIEWS / 4) * GROUP_FLOATS, lane_off);
         const float* wrgb = aux + AUX_HEAD + 256;
         const float* hb = aux + AUX_HEAD + 256 + 384;
         const float r = head_dot<4>(A, wrgb, h) + hb[1];

@@ -224,7 +224,7 @@ NL_HD inline int64_t bwd_source(int use_viewdirs, int output_ch, int64_t idx) {
 // access covers 512 contiguous bytes per lane half, and a workgroup's whole tile is one contiguous
 // region.  The weight-gradient GEMM stages [group][32 points][4 rows] chunks, 512 contiguous bytes per
 // group, and reads a lane's four rows with one ds_read_b128.  n_pts is rounded up to whole tiles;
-// padding points hold zeros.  Rows:
+// padding points hold finite values (their gradients are exactly zero).  Rows:
 //   rows   0.. 63  encoded positions (row 63 zero)        rows 64.. 95  encoded directions (27 used)
 //   rows  96+256*l .. +255  output of pts layer l after ReLU (l = 0..7)
 //   rows 2144..2399 feature_linear output                  rows 2400..2527 views layer output after ReLU
