@@ -76,8 +76,8 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
     }
     Stream st;
     st.ring = ring;
-    st.mine = ring + wave * 4 * BLOCK_FLOATS;
-    st.g = packed_bwd + wave * 4 * BLOCK_FLOATS + lane * 4;
+    st.mine = ring + wave * WAVE_BLOCKS * BLOCK_FLOATS;
+    st.g = packed_bwd + wave * WAVE_BLOCKS * BLOCK_FLOATS + lane * 4;
     st.next = 0;
     st.nslabs = bwd_stream_blocks(VIEWDIRS ? 1 : 0) / SLAB_BLOCKS;
     __syncthreads();

@@ -14,6 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256;
 constexpr int RING_FLOATS = 2 * SLAB_FLOATS;
+constexpr int WAVE_BLOCKS = SLAB_BLOCKS / 4;   // blocks of a slab each of the four waves fetches
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -22,7 +23,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 // The weight stream as seen by one wave: a double-buffered slab ring in LDS.
 struct Stream {
-    const float* g;   // this lane's source pointer for block 4*wave of slab 0
+    const float* g;   // this lane's source pointer for block WAVE_BLOCKS*wave of slab 0
     float* ring;      // LDS ring base
     float* mine;      // this wave's destination inside a slab (wave-uniform)
     int next;         // next slab to consume
@@ -32,7 +33,7 @@ struct Stream {
         const float* src = g + (int64_t)slab * SLAB_FLOATS;
         float* dst = mine + (slab & 1) * SLAB_FLOATS;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
+        for (int b = 0; b < WAVE_BLOCKS; ++b) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
     }
     // Make slab `next` readable, start fetching the one after it, return this lane's read pointer.
     __device__ __forceinline__ const float* advance(int lane) {
@@ -67,7 +68,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int NOUT, int NIN, bool ACCUM, typename InTile>
 __device__ __forceinline__ void run_section(Stream& st, int lane, f32x16 (&acc)[8], InTile in_tile) {
     constexpr int NB = NOUT * NIN * 4, DEPTH = 2;
-    static_assert(NB % SLAB_BLOCKS == 0, "sections are whole slabs");
+    // a section starts on a slab boundary; the last slab of the stream may be partly used (the fetch then
+    // reads on into whatever follows the stream in the packed buffer, which nothing consumes)
     f32x4 abuf[DEPTH + 1];
     const float* cur = nullptr;
     static_for<NB + DEPTH>([&]<int I>() {

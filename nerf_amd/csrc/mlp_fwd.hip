@@ -181,10 +181,10 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
 
     Stream st;
     st.ring = ring;
-    st.mine = ring + wave * 4 * BLOCK_FLOATS;
-    st.g = packed + wave * 4 * BLOCK_FLOATS + lane * 4;
+    st.mine = ring + wave * WAVE_BLOCKS * BLOCK_FLOATS;
+    st.g = packed + wave * WAVE_BLOCKS * BLOCK_FLOATS + lane * 4;
     st.next = 0;
-    st.nslabs = stream_blocks / SLAB_BLOCKS;
+    st.nslabs = (stream_blocks + SLAB_BLOCKS - 1) / SLAB_BLOCKS;
     __syncthreads();  // aux visible; no glds in flight yet
     st.fetch(0);
 

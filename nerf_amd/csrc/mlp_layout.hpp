@@ -24,7 +24,7 @@
 namespace nerflayout {
 
 constexpr int BLOCK_FLOATS = 256;        // 1 KiB
-constexpr int SLAB_BLOCKS = 16;          // blocks staged per LDS buffer
+constexpr int SLAB_BLOCKS = 16;          // blocks staged per LDS buffer (every section starts on a slab boundary)
 constexpr int SLAB_FLOATS = SLAB_BLOCKS * BLOCK_FLOATS;
 constexpr int W = 256;                   // hidden width
 constexpr int IN_PTS = 63, IN_DIRS = 27; // encoded widths (L = 10, L = 4)

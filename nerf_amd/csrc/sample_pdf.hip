@@ -9,8 +9,13 @@
 //      scan order cannot change a bit relative to the sequential fp64 accumulation of ATen's cumsum;
 //   3. per uniform: binary search (searchsorted, right=True), clamp, gather, lerp, in fp32 with
 //      one rounding per op;
-//   4. z_std in fp64; 5. rank sort of the Sc+Si depths (stable, NaN last), coalesced write-out
-//      of z and of the sample positions o + d*z.
+//   4. z_std in fp64;
+//   5. sort(cat(coarse, fine)) as a merge: both lists are checked for order with one ballot each (the
+//      coarse depths always are, the fine ones are whenever the uniforms are, i.e. in every
+//      deterministic render), an unordered list goes through an in-LDS bitonic sort of (order key,
+//      index) pairs, and every element then finds its output slot by one binary search in the other
+//      list; coarse elements precede equal fine ones, NaN sorts last: the order of a stable sort of
+//      the concatenation.  Coalesced write-out of z and of the sample positions o + d*z.
 // HBM traffic per ray: read 8*Sc (+4*Si uniforms), write 4*(Sc+Si) + 4 (+12*(Sc+Si) positions).
 #include "common.hpp"
 #pragma clang fp contract(off)
@@ -77,8 +82,42 @@ __device__ float cascade_row_sum(const float* x, int stride, int k, int count) {
     return acc[0][0];
 }
 
-__device__ __forceinline__ bool lt_nan_last(float a, float b) { return (a < b) || ((b != b) && (a == a)); }
-__device__ __forceinline__ bool eq_nan(float a, float b) { return (a == b) || ((a != a) && (b != b)); }
+// Order-preserving map float -> uint32: ascending, -0 == +0, every NaN last (and equal to every other NaN).
+__device__ __forceinline__ uint32_t order_key(float f) {
+    if (f != f) return 0xffffffffu;
+    if (f == 0.0f) return 0x80000000u;
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__host__ __device__ inline int pow2_at_least(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// keys[i] = (order key << 32) | index for i < count, all-ones padding up to P; returns whether the list is ordered
+__device__ __forceinline__ bool build_keys(uint64_t* keys, const float* vals, int first_index, int count, int P, int lane) {
+    for (int i = lane; i < P; i += 64)
+        keys[i] = i < count ? (((uint64_t)order_key(vals[i]) << 32) | (uint32_t)(first_index + i)) : ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    bool ok = true;
+    for (int i = lane; i + 1 < count; i += 64) ok = ok && (keys[i] < keys[i + 1]);
+    return __all(ok);
+}
+
+// in-LDS bitonic sort of P (a power of two) 64-bit keys by one wavefront
+__device__ __forceinline__ void bitonic_sort(uint64_t* a, int P, int lane) {
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (P >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const uint64_t x = a[i], y = a[l];
+                if ((x > y) == ((i & k) == 0)) { a[i] = y; a[l] = x; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
 
 __global__ void __launch_bounds__(WAVE * WAVES_PER_BLOCK)
 k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict__ z,
@@ -96,6 +135,9 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
     float* cdf = zsorted + Sf4;   // [nb]
     float* bins = cdf + nb4;      // [nb]
     float* wp = bins + nb4;       // [nw] weights + 1e-5, then pdf
+    const int Pc = pow2_at_least(Sc), Ps = pow2_at_least(Si);
+    uint64_t* kc = reinterpret_cast<uint64_t*>(smem + (size_t)WAVES_PER_BLOCK * (2 * Sf4 + 3 * nb4)) + (size_t)wv * (Pc + Ps);
+    uint64_t* ks = kc + Pc;       // (order key, index) of the coarse / fine depths
     const int64_t wave0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
     const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
     for (int64_t ray = wave0; ray < n; ray += nwaves) {
@@ -171,15 +213,23 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
             if (lane == 0) z_std[ray] = (float)sqrt(m2 / (double)Si);
         }
         if (bins_given) { __builtin_amdgcn_wave_barrier(); continue; }
-        // ---- stable rank sort (NaN last) of the Sf depths
+        // ---- sort(cat(coarse, fine)): order each list if it is not ordered yet, then merge by rank
+        if (!build_keys(kc, zs, 0, Sc, Pc, lane)) bitonic_sort(kc, Pc, lane);
+        if (!build_keys(ks, zs + Sc, Sc, Si, Ps, lane)) bitonic_sort(ks, Ps, lane);
+        __builtin_amdgcn_wave_barrier();
         for (int e = lane; e < Sf; e += 64) {
-            const float v = zs[e];
-            int rank = 0;
-            for (int f = 0; f < Sf; ++f) {
-                const float o = zs[f];
-                rank += (lt_nan_last(o, v) || (f < e && eq_nan(o, v))) ? 1 : 0;
+            const bool coarse = e < Sc;
+            const uint64_t me = coarse ? kc[e] : ks[e - Sc];
+            const uint32_t key = (uint32_t)(me >> 32);
+            // coarse: fine elements strictly below;  fine: coarse elements below or equal
+            const uint64_t* other = coarse ? ks : kc;
+            int lo = 0, hi = coarse ? Si : Sc;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t ok = (uint32_t)(other[mid] >> 32);
+                if (coarse ? (ok < key) : (ok <= key)) lo = mid + 1; else hi = mid;
             }
-            zsorted[rank] = v;
+            zsorted[(coarse ? e : e - Sc) + lo] = zs[(uint32_t)me];
         }
         __builtin_amdgcn_wave_barrier();
         for (int s = lane; s < Sf; s += 64) z_out[ray * Sf + s] = zsorted[s];
@@ -211,7 +261,8 @@ int nerf_sample_fine(int64_t n, int Sc, int Si, const float* z, const float* wei
     NERF_REQUIRE(z && weights && u && z_out, "nerf_sample_fine: null pointer");
     NERF_REQUIRE(!pts_out || (rays && ray_stride >= 6), "nerf_sample_fine: pts_out needs rays with stride >= 6");
     const int Sf4 = (Sc + Si + 3) & ~3, nb4 = (Sc - 1 + 3) & ~3;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * (2 * Sf4 + 3 * nb4) * sizeof(float);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * ((2 * Sf4 + 3 * nb4) * sizeof(float) +
+                                                  (size_t)(pow2_at_least(Sc) + pow2_at_least(Si)) * sizeof(uint64_t));
     NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_fine: Sc+Si=%d needs %zu bytes of LDS (> 160 KiB)", Sc + Si, lds);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine),
@@ -234,7 +285,8 @@ int nerf_sample_pdf(int64_t n, int n_bins, int Si, const float* bins, const floa
     NERF_REQUIRE(bins && weights && u && samples, "nerf_sample_pdf: null pointer");
     const int Sc = n_bins + 1;
     const int Sf4 = (Sc + Si + 3) & ~3, nb4 = (n_bins + 3) & ~3;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * (2 * Sf4 + 3 * nb4) * sizeof(float);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * ((2 * Sf4 + 3 * nb4) * sizeof(float) +
+                                                  (size_t)(pow2_at_least(Sc) + pow2_at_least(Si)) * sizeof(uint64_t));
     NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_pdf: n_bins+Si=%d needs %zu bytes of LDS (> 160 KiB)", n_bins + Si, lds);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine),

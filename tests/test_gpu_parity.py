@@ -239,6 +239,49 @@ def test_sample_fine_merge_sort_std(device):
         exact(out["z"], torch.sort(torch.cat([z, smp], -1), -1)[0], "det z")
 
 
+def test_sample_fine_merge_edge_cases(device):
+    """The merge must equal sort(cat(.)) also when the coarse depths arrive unordered, when depths tie (flat weights
+    with deterministic uniforms put fine samples exactly on coarse ones), with NaN (sorts last) and with -0/+0."""
+    from nerf_amd import ops
+    rng = np.random.Generator(np.random.PCG64(18))
+    n, Sc, Si = 32, 16, 24
+    rays = T(rng.normal(size=(n, 11)).astype(np.float32))
+
+    def check(z, w, u, what):
+        mid = 0.5 * (z[..., 1:] + z[..., :-1])
+        smp = O.inverse_cdf(mid, w[..., 1:-1], u if u.dim() == 2 else u.expand(n, -1).contiguous())
+        want, _ = torch.sort(torch.cat([z, smp], -1), -1)
+        out = ops.sample_fine(z.to(device), w.to(device), u.to(device), rays.to(device))
+        got = out["z"].cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), what
+        assert torch.equal(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(want, nan=0.0)), what
+        # signed zeros: same multiset of bit patterns per row
+        gb = np.sort(got.numpy().view(np.uint32), -1)
+        wb = np.sort(want.numpy().view(np.uint32), -1)
+        fin = ~np.isnan(want.numpy()).any(-1)
+        assert np.array_equal(gb[fin], wb[fin]), what
+
+    w = T((rng.uniform(0, 1, size=(n, Sc)) ** 3).astype(np.float32))
+    u = T(rng.uniform(0, 1, size=(n, Si)).astype(np.float32))
+    z_desc = T(-np.sort(-rng.uniform(2, 6, size=(n, Sc)), -1).astype(np.float32))
+    check(z_desc, w, u, "descending coarse depths")
+    z_shuf = T(rng.uniform(2, 6, size=(n, Sc)).astype(np.float32))
+    check(z_shuf, w, u, "unordered coarse depths")
+    z_ties = T(np.round(np.sort(rng.uniform(0, 4, size=(n, Sc)), -1)).astype(np.float32))
+    check(z_ties, torch.ones(n, Sc), ops.cached_linspace(Si, "cpu"), "ties between coarse and fine depths")
+    z_nan = T(np.sort(rng.uniform(2, 6, size=(n, Sc)), -1).astype(np.float32))
+    z_nan[::3, 5] = float("nan")
+    check(z_nan, w, u, "NaN depth")
+    w_nan = w.clone()
+    w_nan[1::4, 3] = float("nan")
+    check(T(np.sort(rng.uniform(2, 6, size=(n, Sc)), -1).astype(np.float32)), w_nan, u, "NaN weights")
+    z_zero = T(np.sort(rng.uniform(-1, 1, size=(n, Sc)), -1).astype(np.float32))
+    z_zero[:, 7] = -0.0
+    z_zero[:, 8] = 0.0
+    z_zero = torch.sort(z_zero, -1)[0]
+    check(z_zero, w, u, "signed zeros")
+
+
 def test_mlp_forward(device):
     g = golden("mlp")
     qf = _query_fn()
