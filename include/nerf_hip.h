@@ -44,6 +44,15 @@ int nerf_check_device(void);            /* 0 if the current HIP device can run t
 int nerf_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w,
                   float* rays_o, float* rays_d, void* stream);
 
+/* The random ray batch of one optimisation step taken straight from the camera, with its target colours:
+ * replaces get_rays + the coords meshgrid / central crop / np.random.choice gather of the reference's training
+ * loop (run_nerf.py:833-854).  pick[k] in [0, win_rows*win_cols) numbers the pixels of a window of the image
+ * row-major (whole image: row0 = col0 = 0, win = H x W); pixels outside [0,H)x[0,W) are the caller's error.
+ * image (optional): [H*W, 3] colours of the same view -> target [n, 3]. */
+int nerf_rays_at(int64_t n, const int64_t* pick, int H, int W, int row0, int col0, int win_rows, int win_cols, float fx,
+                 float fy, float cx, float cy, const float* c2w, const float* image, float* rays_o, float* rays_d,
+                 float* target, void* stream);
+
 /* ndc_rays (run_nerf_helpers.py:230-255) on n rays; sx = -1/(W/(2 focal)), sy = -1/(H/(2 focal))
  * evaluated in double by the caller and rounded to fp32, as the upstream scalar arithmetic does.
  * In-place use (o_out == o_in, d_out == d_in) is allowed. */

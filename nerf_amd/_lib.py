@@ -27,6 +27,7 @@ SIGNATURES = {
     "nerf_last_error": (ctypes.c_char_p, []),
     "nerf_check_device": (_i, []),
     "nerf_get_rays": (_i, [_i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "nerf_rays_at": (_i, [_l, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),
     "nerf_ndc_rays": (_i, [_l, _f, _f, _f, _p, _p, _p, _p, _p]),
     "nerf_pack_rays": (_i, [_l, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _p]),
     "nerf_sample_coarse": (_i, [_l, _i, _p, _i, _p, _p, _i, _p, _p, _p]),

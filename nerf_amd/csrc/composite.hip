@@ -7,6 +7,7 @@
 // roundings up to double rounding), with a scalar carry between tiles.  Ray sums are fp64 wave
 // reductions.  HBM-bound: 24*S + 36 bytes per ray forward, 36*S + 24 backward (+4*S with noise).
 #include "common.hpp"
+#include "wave_ops.hpp"
 #pragma clang fp contract(off)
 
 using namespace nerfhip;
@@ -16,31 +17,7 @@ namespace {
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_TILES = 64;  // backward keeps one carry per 64-sample tile: S <= 4096
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// inclusive product scan over the 64 lanes
-__device__ __forceinline__ double wave_scan_mul(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(v, off, 64);
-        if (lane >= off) v *= o;
-    }
-    return v;
-}
-
-// inclusive sum scan, running from the LAST lane towards lane 0
-__device__ __forceinline__ double wave_rscan_add(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_down(v, off, 64);
-        if (lane + off < 64) v += o;
-    }
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce_f64<OpAdd>(v); }
 
 struct Sample {
     float4 raw;
@@ -90,11 +67,10 @@ k_composite_fwd(int64_t n, int S, const float* __restrict__ raw, const float* __
                 q = load_sample(raw, z, noise, base, s, S, dnorm);
                 keep = (double)q.keep;
             }
-            const double incl = wave_scan_mul(keep, lane);
-            double excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0;
+            const double incl = wave_scan_f64<OpMul>(keep);
+            const double excl = dpp_f64<0x138, 0xf, 0xf>(1.0, incl);   // wave_shr:1, lane 0 keeps the identity
             const float T = (float)(carry * excl);
-            carry *= __shfl(incl, 63, 64);
+            carry *= lane_f64(incl, 63);
             // the reference rounds the running product to fp32 per element but keeps the fp64 value running
             if (live) {
                 const float w = q.alpha * T;
@@ -171,7 +147,7 @@ k_composite_bwd(int64_t n, int S, const float* __restrict__ raw, const float* __
                 const int s = t * 64 + lane;
                 double keep = 1.0;
                 if (s < S) keep = (double)load_sample(raw, z, noise, base, s, S, dnorm).keep;
-                carry *= __shfl(wave_scan_mul(keep, lane), 63, 64);
+                carry *= wave_reduce_f64<OpMul>(keep);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -190,16 +166,16 @@ k_composite_bwd(int64_t n, int S, const float* __restrict__ raw, const float* __
                 G = (((gr * sr + gg * sg) + gb * sb) + gd * q.z) + ga;
                 if (g_weights) G = G + g_weights[base + s];
             }
-            const double incl_p = wave_scan_mul(keep, lane);
-            double excl_p = __shfl_up(incl_p, 1, 64);
-            if (lane == 0) excl_p = 1.0;
+            const double incl_p = wave_scan_f64<OpMul>(keep);
+            const double excl_p = dpp_f64<0x138, 0xf, 0xf>(1.0, incl_p);   // wave_shr:1
             const float T = (float)(carry_in[t] * excl_p);
+            // sum of G_j w_j over the later samples = tile total - inclusive prefix (fp64: the cancellation is far
+            // below the fp32 result's resolution) + everything in later tiles
             const double gw = (double)G * (double)w;
-            const double incl = wave_rscan_add(gw, lane);
-            double after = __shfl_down(incl, 1, 64);
-            if (lane == 63) after = 0.0;
-            after += suffix;
-            suffix += __shfl(incl, 0, 64);
+            const double incl = wave_scan_f64<OpAdd>(gw);
+            const double total = lane_f64(incl, 63);
+            const double after = (total - incl) + suffix;
+            suffix += total;
             if (live) {
                 float4 o;
                 o.x = w * gr * (sr * (1.0f - sr));

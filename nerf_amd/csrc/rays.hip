@@ -12,21 +12,47 @@ using namespace nerfhip;
 namespace {
 
 // run_nerf_helpers.py:169-196.  dirs = [(i-cx)/fx, -(j-cy)/fy, -1]; d = sum_k dirs[k] * c2w[r][k].
+// IDX = uint32_t whenever the element count allows it: the index divisions are a fifth of the 64-bit ones.
+template <typename IDX>
 __global__ void __launch_bounds__(256) k_get_rays(int H, int W, float fx, float fy, float cx, float cy,
                                                   const float* __restrict__ c2w, float* __restrict__ rays_o,
                                                   float* __restrict__ rays_d) {
-    const int64_t total = (int64_t)H * W * 3;
+    const IDX total = (IDX)H * (IDX)W * 3;
     // one thread per output float: stores of a wave are 256 contiguous bytes in each array
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t pix = e / 3;
+    for (IDX e = (IDX)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (IDX)gridDim.x * blockDim.x) {
+        const IDX pix = e / 3;
         const int r = (int)(e - pix * 3);
-        const int j = (int)(pix / W), i = (int)(pix - (int64_t)j * W);
+        const int j = (int)(pix / (IDX)W), i = (int)(pix - (IDX)j * (IDX)W);
         const float dx = ((float)i - cx) / fx;
         const float dy = -(((float)j - cy) / fy);
         const float dz = -1.0f;
         const float m0 = c2w[r * 4 + 0], m1 = c2w[r * 4 + 1], m2 = c2w[r * 4 + 2];
         rays_d[e] = (dx * m0 + dy * m1) + dz * m2;
         rays_o[e] = c2w[r * 4 + 3];
+    }
+}
+
+// The ray batch of one optimisation step taken straight from the camera (run_nerf.py:833-854): ray k goes
+// through pixel (row0 + q / win_cols, col0 + q % win_cols), q = pick[k], of a win_rows x win_cols window of
+// the image (the whole image, or the central crop of the first iterations).  Same arithmetic as k_get_rays,
+// so the rays equal get_rays(...)[row, col] bit for bit; the target colour is gathered in the same pass.
+__global__ void __launch_bounds__(256) k_rays_at(int64_t n, const int64_t* __restrict__ pick, int W, int row0, int col0,
+                                                 int win_cols, float fx, float fy, float cx, float cy,
+                                                 const float* __restrict__ c2w, const float* __restrict__ image,
+                                                 float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                 float* __restrict__ target) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * 3; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / 3;
+        const int r = (int)(e - k * 3);
+        const int64_t q = pick[k];
+        const int j = row0 + (int)(q / win_cols), i = col0 + (int)(q % win_cols);
+        const float dx = ((float)i - cx) / fx;
+        const float dy = -(((float)j - cy) / fy);
+        const float dz = -1.0f;
+        const float m0 = c2w[r * 4 + 0], m1 = c2w[r * 4 + 1], m2 = c2w[r * 4 + 2];
+        rays_d[e] = (dx * m0 + dy * m1) + dz * m2;
+        rays_o[e] = c2w[r * 4 + 3];
+        if (image) target[e] = image[((int64_t)j * W + i) * 3 + r];
     }
 }
 
@@ -52,15 +78,16 @@ __global__ void __launch_bounds__(256) k_ndc(int64_t n, float sx, float sy, floa
 }
 
 // run_nerf.py:419-453.  One thread per (ray, sample).
+template <typename IDX>
 __global__ void __launch_bounds__(256) k_sample_coarse(int64_t n, int S, const float* __restrict__ rays, int ld,
                                                        const float* __restrict__ t_vals,
                                                        const float* __restrict__ t_rand, int lindisp,
                                                        float* __restrict__ z_out, float* __restrict__ pts) {
-    const int64_t total = n * S;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t ray = e / S;
-        const int s = (int)(e - ray * S);
-        const float* rr = rays + ray * ld;
+    const IDX total = (IDX)n * (IDX)S;
+    for (IDX e = (IDX)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (IDX)gridDim.x * blockDim.x) {
+        const IDX ray = e / (IDX)S;
+        const int s = (int)(e - ray * (IDX)S);
+        const float* rr = rays + (int64_t)ray * ld;
         const float near = rr[6], far = rr[7];
         auto depth = [&](int k) -> float {
             const float t = t_vals[k];
@@ -75,9 +102,10 @@ __global__ void __launch_bounds__(256) k_sample_coarse(int64_t n, int S, const f
         }
         z_out[e] = z;
         if (pts) {
-            pts[e * 3 + 0] = rr[0] + rr[3] * z;
-            pts[e * 3 + 1] = rr[1] + rr[4] * z;
-            pts[e * 3 + 2] = rr[2] + rr[5] * z;
+            float* pp = pts + (int64_t)e * 3;
+            pp[0] = rr[0] + rr[3] * z;
+            pp[1] = rr[1] + rr[4] * z;
+            pp[2] = rr[2] + rr[5] * z;
         }
     }
 }
@@ -145,9 +173,30 @@ int nerf_get_rays(int H, int W, float fx, float fy, float cx, float cy, const fl
     NERF_REQUIRE(H > 0 && W > 0, "nerf_get_rays: H=%d W=%d", H, W);
     NERF_REQUIRE(c2w && rays_o && rays_d, "nerf_get_rays: null pointer");
     NERF_REQUIRE(fx != 0.0f && fy != 0.0f, "nerf_get_rays: zero focal length");
-    hipLaunchKernelGGL(k_get_rays, dim3(grid_for((int64_t)H * W * 3)), dim3(256), 0, as_stream(stream), H, W, fx, fy,
-                       cx, cy, c2w, rays_o, rays_d);
+    const int64_t total = (int64_t)H * W * 3;
+    if (total < (int64_t)0x7fffffff)
+        hipLaunchKernelGGL(k_get_rays<uint32_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), H, W, fx, fy, cx, cy,
+                           c2w, rays_o, rays_d);
+    else
+        hipLaunchKernelGGL(k_get_rays<int64_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), H, W, fx, fy, cx, cy,
+                           c2w, rays_o, rays_d);
     return launched("nerf_get_rays");
+}
+
+int nerf_rays_at(int64_t n, const int64_t* pick, int H, int W, int row0, int col0, int win_rows, int win_cols, float fx,
+                 float fy, float cx, float cy, const float* c2w, const float* image, float* rays_o, float* rays_d,
+                 float* target, void* stream) {
+    NERF_REQUIRE(n >= 0, "nerf_rays_at: n=%lld", (long long)n);
+    NERF_REQUIRE(H > 0 && W > 0 && win_rows > 0 && win_cols > 0 && row0 >= 0 && col0 >= 0 && row0 + win_rows <= H &&
+                 col0 + win_cols <= W, "nerf_rays_at: window %dx%d at (%d,%d) does not fit a %dx%d image", win_rows,
+                 win_cols, row0, col0, H, W);
+    NERF_REQUIRE(fx != 0.0f && fy != 0.0f, "nerf_rays_at: zero focal length");
+    if (n == 0) return 0;
+    NERF_REQUIRE(pick && c2w && rays_o && rays_d, "nerf_rays_at: null pointer");
+    NERF_REQUIRE(!image || target, "nerf_rays_at: image given without a target buffer");
+    hipLaunchKernelGGL(k_rays_at, dim3(grid_for(n * 3)), dim3(256), 0, as_stream(stream), n, pick, W, row0, col0, win_cols,
+                       fx, fy, cx, cy, c2w, image, rays_o, rays_d, target);
+    return launched("nerf_rays_at");
 }
 
 int nerf_ndc_rays(int64_t n, float sx, float sy, float near, const float* o_in, const float* d_in, float* o_out,
@@ -178,8 +227,12 @@ int nerf_sample_coarse(int64_t n, int S, const float* rays, int ray_stride, cons
     NERF_REQUIRE(ray_stride >= 8, "nerf_sample_coarse: ray_stride=%d < 8", ray_stride);
     if (n == 0) return 0;
     NERF_REQUIRE(rays && t_vals && z, "nerf_sample_coarse: null pointer");
-    hipLaunchKernelGGL(k_sample_coarse, dim3(grid_for(n * S)), dim3(256), 0, as_stream(stream), n, S, rays, ray_stride,
-                       t_vals, t_rand, lindisp, z, pts);
+    if (n * S < (int64_t)0x7fffffff)
+        hipLaunchKernelGGL(k_sample_coarse<uint32_t>, dim3(grid_for(n * S)), dim3(256), 0, as_stream(stream), n, S, rays,
+                           ray_stride, t_vals, t_rand, lindisp, z, pts);
+    else
+        hipLaunchKernelGGL(k_sample_coarse<int64_t>, dim3(grid_for(n * S)), dim3(256), 0, as_stream(stream), n, S, rays,
+                           ray_stride, t_vals, t_rand, lindisp, z, pts);
     return launched("nerf_sample_coarse");
 }
 

@@ -18,6 +18,7 @@
 //      the concatenation.  Coalesced write-out of z and of the sample positions o + d*z.
 // HBM traffic per ray: read 8*Sc (+4*Si uniforms), write 4*(Sc+Si) + 4 (+12*(Sc+Si) positions).
 #include "common.hpp"
+#include "wave_ops.hpp"
 #pragma clang fp contract(off)
 
 using namespace nerfhip;
@@ -26,20 +27,7 @@ namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ double wave_scan_add(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_reduce_f64<OpAdd>(v); }
 
 // ATen row_sum over `count` items x[(r)*stride + k], r = 0..count-1 (aten/src/ATen/native/cpu/SumKernel.cpp:
 // 4 interleaved accumulators, each a 4-level cascade with level step >= 16).
@@ -173,9 +161,9 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
             const int s = s0 + lane;
             double p = 0.0;
             if (s < nw) p = (double)(wp[s] / total);
-            const double incl = wave_scan_add(p, lane);
+            const double incl = wave_scan_f64<OpAdd>(p);
             if (s < nw) cdf[s + 1] = (float)(carry + incl);
-            carry += __shfl(incl, 63, 64);
+            carry += lane_f64(incl, 63);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- invert the cdf

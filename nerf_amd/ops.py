@@ -82,6 +82,28 @@ def get_rays(H: int, W: int, fx: float, fy: float, cx: float, cy: float, c2w: to
     return o, d
 
 
+def rays_at(pick: torch.Tensor, H: int, W: int, window, fx: float, fy: float, cx: float, cy: float, c2w: torch.Tensor,
+            image: Optional[torch.Tensor] = None):
+    """Rays (and target colours) of the pixels pick[k] of a window (row0, col0, rows, cols) of one view."""
+    c2w = _f32c(to_dev(c2w)[:3, :4], "c2w")
+    if not (pick.is_cuda and pick.dtype == torch.int64):
+        raise TypeError(f"pick: expected an int64 tensor on a HIP device, got {pick.dtype} on {pick.device}")
+    pick = pick.contiguous()
+    n = pick.numel()
+    row0, col0, rows, cols = [int(v) for v in window]
+    o = torch.empty((n, 3), dtype=torch.float32, device=c2w.device)
+    d = torch.empty_like(o)
+    target = None
+    if image is not None:
+        image = _f32c(image, "image")
+        assert image.numel() == H * W * 3, (image.shape, H, W)
+        target = torch.empty_like(o)
+    with torch.cuda.device(c2w.device), _timed("rays_at", n * (8 + 24 + (24 if image is not None else 0))):
+        check(lib.nerf_rays_at(n, pick.data_ptr(), H, W, row0, col0, rows, cols, fx, fy, cx, cy, c2w.data_ptr(),
+                               _ptr(image), o.data_ptr(), d.data_ptr(), _ptr(target), _stream()))
+    return o, d, target
+
+
 def ndc_rays(sx: float, sy: float, near: float, rays_o: torch.Tensor, rays_d: torch.Tensor):
     o, d = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d")
     oo, od = torch.empty_like(o), torch.empty_like(d)

@@ -32,6 +32,11 @@ def _world(group=None) -> Tuple[int, int]:
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def rank_world(group=None) -> Tuple[int, int]:
+    """(rank, world size); (0, 1) when torch.distributed is not initialised."""
+    return _world(group)
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Concatenate per-rank row blocks cut by shard_bounds (blocks differ by at most one row)."""
     rank, world = _world(group)

@@ -97,7 +97,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
 
 
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
-    """run_nerf.py:163-201.  PNG writing needs imageio, which is imported only when savedir is given."""
+    """run_nerf.py:163-201.  Frames are written as PNG with PIL when savedir is given."""
     H, W, focal = hwf
     if render_factor != 0:
         H = H // render_factor
@@ -115,8 +115,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         if i == 0:
             print(rgb.shape, disp.shape)
         if savedir is not None:
-            import imageio
-            imageio.imwrite(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))  # noqa: F405
+            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))  # noqa: F405
     return np.stack(rgbs, 0), np.stack(disps, 0)
 
 
@@ -358,4 +357,172 @@ def config_parser():
     parser.add_argument("--i_weights", type=int, default=10000, help='frequency of weight ckpt saving')
     parser.add_argument("--i_testset", type=int, default=50000, help='frequency of testset saving')
     parser.add_argument("--i_video", type=int, default=50000, help='frequency of render_poses video saving')
+    # not upstream (the upstream loop is hard-wired to 200001 iterations)
+    parser.add_argument("--N_iters", type=int, default=200000 + 1, help='last iteration + 1')
     return parser
+
+
+# ------------------------------------------------------------------------------------------------
+# training driver (run_nerf.py:607-971)
+# ------------------------------------------------------------------------------------------------
+def _write_png(path, rgb8):
+    from PIL import Image
+    Image.fromarray(rgb8).save(path)
+
+
+def _save_frames(prefix, frames8):
+    """Video frames as numbered PNGs (there is no mp4 writer among this package's dependencies)."""
+    os.makedirs(prefix, exist_ok=True)
+    for k, fr in enumerate(frames8):
+        _write_png(os.path.join(prefix, '{:03d}.png'.format(k)), fr)
+
+
+def load_dataset(args):
+    """-> images, poses, render_poses, hwf, K, (i_train, i_val, i_test), near, far  (run_nerf.py:612-701)."""
+    from . import datasets
+    K = None
+    if args.dataset_type == 'llff':
+        images, poses, bds, render_poses, i_test = datasets.load_llff_data(args.datadir, args.factor, recenter=True,
+                                                                           bd_factor=.75, spherify=args.spherify)
+        hwf = poses[0, :3, -1]
+        poses = poses[:, :3, :4]
+        print('Loaded llff', images.shape, render_poses.shape, hwf, args.datadir)
+        if not isinstance(i_test, list):
+            i_test = [i_test]
+        if args.llffhold > 0:
+            print('Auto LLFF holdout,', args.llffhold)
+            i_test = np.arange(images.shape[0])[::args.llffhold]
+        i_val = i_test
+        i_train = np.array([i for i in np.arange(int(images.shape[0])) if (i not in i_test and i not in i_val)])
+        print('DEFINING BOUNDS')
+        if args.no_ndc:
+            near, far = np.ndarray.min(bds) * .9, np.ndarray.max(bds) * 1.
+        else:
+            near, far = 0., 1.
+        print('NEAR FAR', near, far)
+    elif args.dataset_type == 'blender':
+        images, poses, render_poses, hwf, i_split = datasets.load_blender_data(args.datadir, args.half_res, args.testskip)
+        print('Loaded blender', images.shape, render_poses.shape, hwf, args.datadir)
+        i_train, i_val, i_test = i_split
+        near, far = 2., 6.
+        if args.white_bkgd:
+            images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:])
+        else:
+            images = images[..., :3]
+    else:
+        raise NotImplementedError(f"dataset_type '{args.dataset_type}': this package reads 'blender' and 'llff' scenes")
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    hwf = [H, W, focal]
+    if K is None:
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    return images, poses, render_poses, hwf, K, (i_train, i_val, i_test), near, far
+
+
+def train(argv=None):
+    """The upstream optimisation driver: data, log directory, models, ray batches, the step, checkpoints and
+    periodic test renders.  Under torch.distributed (one process per GPU) the step is data parallel: every rank
+    draws its own N_rand rays, gradients are averaged with one all-reduce, rank 0 writes the files."""
+    from . import parallel
+    from .raybatch import RayShuffler, ViewSampler
+    args = config_parser().parse_args(argv)
+    dev = ops.device()
+    rank, world = parallel.rank_world()
+    images, poses, render_poses, hwf, K, (i_train, i_val, i_test), near, far = load_dataset(args)
+    H, W, focal = hwf
+    if args.render_test:
+        render_poses = np.array(poses[i_test])
+
+    basedir, expname = args.basedir, args.expname
+    os.makedirs(os.path.join(basedir, expname), exist_ok=True)
+    if rank == 0:
+        with open(os.path.join(basedir, expname, 'args.txt'), 'w') as fh:
+            for arg in sorted(vars(args)):
+                fh.write('{} = {}\n'.format(arg, getattr(args, arg)))
+        if args.config is not None:
+            with open(os.path.join(basedir, expname, 'config.txt'), 'w') as fh:
+                fh.write(open(args.config, 'r').read())
+
+    render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer = create_nerf(args)
+    global_step = start
+    bds_dict = {'near': near, 'far': far}
+    render_kwargs_train.update(bds_dict)
+    render_kwargs_test.update(bds_dict)
+    if world > 1:
+        parallel.broadcast_parameters(grad_vars)
+    render_poses = torch.Tensor(np.asarray(render_poses)).to(dev)
+
+    if args.render_only:
+        print('RENDER ONLY')
+        with torch.no_grad():
+            gt = images[i_test] if args.render_test else None
+            testsavedir = os.path.join(basedir, expname, 'renderonly_{}_{:06d}'.format('test' if args.render_test else 'path', start))
+            os.makedirs(testsavedir, exist_ok=True)
+            print('test poses shape', render_poses.shape)
+            rgbs, _ = render_path(render_poses, hwf, K, args.chunk, render_kwargs_test, gt_imgs=gt, savedir=testsavedir,
+                                  render_factor=args.render_factor)
+            print('Done rendering', testsavedir)
+        return rgbs
+
+    N_rand = args.N_rand
+    if not args.no_batching:
+        print('get rays')
+        batcher = RayShuffler(images, poses, i_train, H, W, K, N_rand, device=dev, seed=0, rank=rank, world_size=world)
+        print('done')
+    else:
+        batcher = ViewSampler(images, poses, i_train, H, W, K, N_rand, args.precrop_iters, args.precrop_frac, device=dev,
+                              seed=rank)
+        if args.precrop_iters > 0:
+            w = batcher.window(0)
+            print(f"[Config] Center cropping of size {w[2]} x {w[3]} is enabled until iter {args.precrop_iters}")
+    poses_dev = torch.Tensor(np.asarray(poses)).to(dev)
+
+    print('Begin')
+    print('TRAIN views are', i_train)
+    print('TEST views are', i_test)
+    print('VAL views are', i_val)
+    loss = psnr = None
+    for i in range(start + 1, args.N_iters):
+        batch_rays, target_s = batcher.next() if not args.no_batching else batcher.next(i)
+
+        rgb, disp, acc, extras = render(H, W, K, chunk=args.chunk, rays=batch_rays, verbose=i < 10, retraw=True,
+                                        **render_kwargs_train)
+        optimizer.zero_grad()
+        img_loss = img2mse(rgb, target_s)  # noqa: F405
+        loss = img_loss
+        psnr = mse2psnr(img_loss)  # noqa: F405
+        if 'rgb0' in extras:
+            loss = loss + img2mse(extras['rgb0'], target_s)  # noqa: F405
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_gradients(grad_vars)
+        optimizer.step()
+
+        new_lrate = args.lrate * (0.1 ** (global_step / (args.lrate_decay * 1000)))
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = new_lrate
+
+        if rank == 0:
+            if i % args.i_weights == 0:
+                path = os.path.join(basedir, expname, '{:06d}.tar'.format(i))
+                save_checkpoint(path, global_step, render_kwargs_train, optimizer)
+                print('Saved checkpoints at', path)
+            if i % args.i_video == 0 and i > 0:
+                with torch.no_grad():
+                    rgbs, disps = render_path(render_poses, hwf, K, args.chunk, render_kwargs_test)
+                print('Done, saving', rgbs.shape, disps.shape)
+                moviebase = os.path.join(basedir, expname, '{}_spiral_{:06d}_'.format(expname, i))
+                _save_frames(moviebase + 'rgb', to8b(rgbs))  # noqa: F405
+                _save_frames(moviebase + 'disp', to8b(disps / np.max(disps)))  # noqa: F405
+            if i % args.i_testset == 0 and i > 0:
+                testsavedir = os.path.join(basedir, expname, 'testset_{:06d}'.format(i))
+                os.makedirs(testsavedir, exist_ok=True)
+                print('test poses shape', poses_dev[i_test].shape)
+                with torch.no_grad():
+                    render_path(poses_dev[i_test], hwf, K, args.chunk, render_kwargs_test, gt_imgs=images[i_test],
+                                savedir=testsavedir)
+                print('Saved test set')
+            if i % args.i_print == 0:
+                print(f"[TRAIN] Iter: {i} Loss: {loss.item()}  PSNR: {psnr.item()}")
+        global_step += 1
+    return None if loss is None else float(loss.detach())

@@ -1,0 +1,129 @@
+"""Ray batchers and the training driver on the GPU (synthetic scenes written by the tests)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden  # noqa: F401
+from test_datasets import write_blender_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _camera(H, W, focal):
+    return np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+
+
+def test_rays_at_equals_get_rays_gather(device):
+    from nerf_amd import ops
+    from nerf_amd.datasets import pose_spherical
+    from nerf_amd.run_nerf_helpers import get_rays
+    H, W = 37, 53
+    K = _camera(H, W, 61.7)
+    pose = pose_spherical(40.0, -25.0, 3.5)[:3, :4].to(device)
+    image = torch.rand(H, W, 3, device=device)
+    ro, rd = get_rays(H, W, K, pose)
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    for win in ((0, 0, H, W), (H // 2 - 9, W // 2 - 13, 18, 26)):
+        n_pix = win[2] * win[3]
+        pick = torch.randperm(n_pix, device=device, generator=g)[:200]
+        o, d, t = ops.rays_at(pick, H, W, win, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), pose, image)
+        rows = win[0] + pick // win[3]
+        cols = win[1] + pick % win[3]
+        assert torch.equal(o, ro[rows, cols]) and torch.equal(d, rd[rows, cols]) and torch.equal(t, image[rows, cols])
+    with pytest.raises(RuntimeError):
+        ops.rays_at(pick, H, W, (0, 0, H + 1, W), 1.0, 1.0, 0.0, 0.0, pose)
+
+
+def test_view_sampler_crop_window_and_distinct_pixels(device):
+    from nerf_amd.datasets import pose_spherical
+    from nerf_amd.raybatch import ViewSampler
+    H, W = 40, 60
+    K = _camera(H, W, 70.0)
+    images = np.random.default_rng(0).uniform(0, 1, (3, H, W, 3)).astype(np.float32)
+    # make every pixel's colour identify it: r = row / H, g = col / W
+    images[..., 0] = (np.arange(H)[:, None] / H)
+    images[..., 1] = (np.arange(W)[None, :] / W)
+    poses = np.stack([pose_spherical(20.0 * k, -30.0, 4.0).numpy() for k in range(3)], 0)
+    vs = ViewSampler(images, poses, [0, 2], H, W, K, N_rand=150, precrop_iters=5, precrop_frac=0.5, device=device, seed=3)
+    assert vs.window(0) == (10, 15, 20, 30) and vs.window(5) == (0, 0, H, W)
+    rays, target = vs.next(0)
+    assert rays.shape == (2, 150, 3) and target.shape == (150, 3)
+    rows = torch.round(target[:, 0] * H).long().cpu().numpy()
+    cols = torch.round(target[:, 1] * W).long().cpu().numpy()
+    assert rows.min() >= 10 and rows.max() < 30 and cols.min() >= 15 and cols.max() < 45
+    assert len(set(zip(rows.tolist(), cols.tolist()))) == 150
+    rays, target = vs.next(7, img_i=2)
+    rows = torch.round(target[:, 0] * H).long()
+    cols = torch.round(target[:, 1] * W).long()
+    from nerf_amd.run_nerf_helpers import get_rays
+    ro, rd = get_rays(H, W, K, torch.from_numpy(poses[2, :3, :4]))
+    assert torch.equal(rays[1], rd[rows, cols]) and torch.equal(rays[0], ro[rows, cols])
+
+
+def test_ray_shuffler_epoch_and_rank_slices(device):
+    from nerf_amd.datasets import pose_spherical
+    from nerf_amd.raybatch import RayShuffler
+    from nerf_amd.run_nerf_helpers import get_rays_np
+    H, W = 6, 8
+    K = _camera(H, W, 9.0)
+    rng = np.random.default_rng(1)
+    images = rng.uniform(0, 1, (4, H, W, 3)).astype(np.float32)
+    poses = np.stack([pose_spherical(25.0 * k, -30.0, 4.0).numpy() for k in range(4)], 0)
+    i_train = [0, 1, 3]
+    want = []
+    for i in i_train:
+        ro, rd = get_rays_np(H, W, K, poses[i, :3, :4])
+        want.append(np.stack([ro, rd, images[i]], -2).reshape(-1, 3, 3).astype(np.float32))
+    want = np.concatenate(want, 0)
+    a = RayShuffler(images, poses, i_train, H, W, K, N_rand=16, device=device, seed=5, rank=0, world_size=2)
+    b = RayShuffler(images, poses, i_train, H, W, K, N_rand=16, device=device, seed=5, rank=1, world_size=2)
+    seen = []
+    for _ in range(want.shape[0] // 32):
+        (ra, ta), (rb, tb) = a.next(), b.next()
+        assert ra.shape == (2, 16, 3) and ta.shape == (16, 3)
+        seen += [torch.cat([ra.transpose(0, 1), ta[:, None]], 1), torch.cat([rb.transpose(0, 1), tb[:, None]], 1)]
+    seen = torch.cat(seen, 0).cpu().numpy()
+    # one epoch of both ranks = distinct records of the training set, every one exactly as the host builds them
+    key = lambda r: r.reshape(r.shape[0], -1)
+    all_rows = {row.tobytes() for row in key(want)}
+    got_rows = [row.tobytes() for row in key(seen)]
+    assert len(set(got_rows)) == len(got_rows) and set(got_rows) <= all_rows
+    assert a.epochs == 1 and b.epochs == 1
+
+
+def test_train_driver_runs_checkpoints_and_resumes(device, tmp_path, capsys):
+    from nerf_amd.run_nerf import train
+    scene = os.path.join(tmp_path, "scene")
+    write_blender_scene(scene, n=(3, 1, 1), size=16)
+    cfg = os.path.join(tmp_path, "tiny.txt")
+    with open(cfg, "w") as fh:
+        fh.write("expname = tiny\nbasedir = %s\ndatadir = %s\ndataset_type = blender\nno_batching = True\n"
+                 "use_viewdirs = True\nwhite_bkgd = True\nlrate_decay = 500\nN_samples = 8\nN_importance = 8\nN_rand = 64\n"
+                 "precrop_iters = 2\nprecrop_frac = 0.5\n" % (os.path.join(tmp_path, "logs"), scene))
+    common = ["--config", cfg, "--i_print", "2", "--i_weights", "4", "--i_testset", "4", "--i_video", "1000", "--testskip", "1"]
+    loss = train(common + ["--N_iters", "5"])
+    assert np.isfinite(loss)
+    log = os.path.join(tmp_path, "logs", "tiny")
+    assert os.path.exists(os.path.join(log, "args.txt")) and os.path.exists(os.path.join(log, "config.txt"))
+    assert os.path.exists(os.path.join(log, "000004.tar")) and os.path.exists(os.path.join(log, "testset_000004", "000.png"))
+    ck = torch.load(os.path.join(log, "000004.tar"), map_location="cpu", weights_only=True)
+    assert set(ck) == {"global_step", "network_fn_state_dict", "network_fine_state_dict", "optimizer_state_dict"}
+    assert ck["global_step"] == 3                       # saved before the step counter moves (run_nerf.py:890-898, 971)
+    out = capsys.readouterr().out
+    assert "Center cropping of size 8 x 8" in out and "[TRAIN] Iter: 4" in out
+    # resume: picks the checkpoint up and continues from its step
+    train(common + ["--N_iters", "7", "--no_batching"])
+    out = capsys.readouterr().out
+    assert "Reloading from" in out and "[TRAIN] Iter: 6" in out
+    # batching mode (all training pixels shuffled) in its own experiment, then render_only from the first one
+    cfg_b = os.path.join(tmp_path, "tiny_b.txt")
+    with open(cfg_b, "w") as fh:
+        fh.write(open(cfg).read().replace("no_batching = True\n", "").replace("expname = tiny", "expname = tiny_b"))
+    assert np.isfinite(train(["--config", cfg_b, "--N_iters", "4", "--testskip", "1", "--i_print", "1"]))
+    assert "[TRAIN] Iter: 3" in capsys.readouterr().out
+    rgbs = train(common + ["--render_only", "--render_factor", "2"])
+    assert rgbs.shape == (40, 8, 8, 3)
+    assert os.path.exists(os.path.join(log, "renderonly_path_000006", "039.png"))
