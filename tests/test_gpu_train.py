@@ -126,4 +126,4 @@ def test_train_driver_runs_checkpoints_and_resumes(device, tmp_path, capsys):
     assert "[TRAIN] Iter: 3" in capsys.readouterr().out
     rgbs = train(common + ["--render_only", "--render_factor", "2"])
     assert rgbs.shape == (40, 8, 8, 3)
-    assert os.path.exists(os.path.join(log, "renderonly_path_000006", "039.png"))
+    assert os.path.exists(os.path.join(log, "renderonly_path_000003", "039.png"))
