@@ -6,7 +6,8 @@
 //   * a workgroup is EIGHT waves (256 points), two per SIMD, each under 256 registers: while one wave of a
 //     SIMD runs its VALU epilogue (bias, ReLU, bf16 rounding) the other keeps the matrix pipe busy, and
 //     the L2 -> LDS weight traffic per point is half that of a four-wave group;
-//   * after bias + ReLU (fp32, VALU) the accumulators are rounded to bf16 and packed pairwise; registers
+//   * after ReLU (fp32, VALU; the bias is the accumulator's initial value) the accumulators are rounded to bf16
+//     and packed pairwise, in the shadow of the next tile's MFMAs; registers
 //     8s..8s+7 of an accumulator tile are exactly the B fragment of k-step s of the next layer
 //     (k = 16s + 8(j>>2) + 4*half + (j&3)), so again no data leaves the register file.  The stream is
 //     the fp32 stream re-blocked (two fp32 blocks -> one 1 KiB block of 64 lanes x 8 bf16);
@@ -74,17 +75,56 @@ __device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, 
 }
 
 // One layer: for every 32-row output tile, NKS MFMAs (k-steps of 16) on the input fragments, then the tile's
-// epilogue on the VALU: y = max(acc + bias, lo) (lo = 0: ReLU, -inf: none), optional head rows as fp32 dot
-// products with y, and y rounded to bf16 into the two B fragments the next layer reads (Y[2*to], Y[2*to+1]).
-// Only one accumulator tile is live; the other wave of the SIMD covers the epilogue's matrix-pipe bubble.
-// Blocks are read DEPTH ahead, also across tiles and slab barriers.  Every layer starts on a slab boundary.
+// epilogue on the VALU: y = max(acc, lo) (lo = 0: ReLU, -inf: none), optional head rows as fp32 dot products
+// with y, and y rounded to bf16 into the two B fragments the next layer reads (Y[2*to], Y[2*to+1]).
+// Two accumulator tiles alternate, and the epilogue is cut into eight pieces (two registers -> one packed
+// dword each) issued one per k-step behind the first eight MFMAs of the NEXT tile, so it runs in the shadow
+// of the matrix pipe instead of stalling it; only a layer's last tile is finished in the open.  The bias is
+// not added afterwards: an accumulator starts as the tile's bias column, read from LDS straight into its
+// registers while the previous tile is still multiplying (layers with at least 12 k-steps; the 4-step first
+// layer adds it in the epilogue).  Weight blocks are read DEPTH ahead, also across tiles and slab barriers.
+// Every layer starts on a slab boundary.
 template <int NOUT, int NKS, int NHEAD, bool STORE, typename InFrag>
 __device__ __forceinline__ void layer16(Stream16& st, int lane, int h, const char*& cur, InFrag in_frag, bf16x8 (&Y)[16],
                                         const float* bias_lds, float lo, const float* head_lds, int head_stride,
                                         float (&head)[3]) {
     constexpr int NB = NOUT * NKS, DEPTH = 3;
+    constexpr bool BIAS_INIT = NKS >= 12;
+    constexpr int PPS = NKS >= 8 ? 1 : 8 / NKS;   // epilogue pieces per k-step
     bf16x8 abuf[DEPTH + 1];
-    f32x16 acc;
+    f32x16 acc[2];
+    const float* bp = bias_lds + h * 16;
+    const float* hp = head_lds + h * 16;
+
+    auto load_bias = [&]<int TO, int Q>() {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + TO * 32 + 4 * Q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[TO & 1][4 * Q + e] = bb[e];
+    };
+    auto piece = [&]<int TP, int K>() {
+        float v0 = acc[TP & 1][2 * K], v1 = acc[TP & 1][2 * K + 1];
+        if constexpr (!BIAS_INIT) {
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(bp + TP * 32 + 2 * K);
+            v0 += bb[0];
+            v1 += bb[1];
+        }
+        v0 = fmaxf(v0, lo);
+        v1 = fmaxf(v1, lo);
+#pragma unroll
+        for (int k = 0; k < NHEAD; ++k) {
+            const f32x2 w = *reinterpret_cast<const f32x2*>(hp + k * head_stride + TP * 32 + 2 * K);
+            head[k] = fmaf(v1, w[1], fmaf(v0, w[0], head[k]));
+            // pin the head sums here: left alone the optimiser sinks all their FMAs to the kernel's end and keeps
+            // (spills) every fp32 activation until then
+            asm volatile("" : "+v"(head[k]));
+        }
+        if constexpr (STORE) {
+            Y[2 * TP + (K >> 2)][2 * (K & 3)] = (__bf16)v0;
+            Y[2 * TP + (K >> 2)][2 * (K & 3) + 1] = (__bf16)v1;
+        }
+    };
+
+    if constexpr (BIAS_INIT) static_for<4>([&]<int Q>() { load_bias.template operator()<0, Q>(); });
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
             if constexpr (I % SLAB16 == 0) cur = st.advance(lane);
@@ -94,40 +134,23 @@ __device__ __forceinline__ void layer16(Stream16& st, int lane, int h, const cha
             constexpr int b = I - DEPTH;
             constexpr int to = b / NKS, ks = b % NKS;
             const bf16x8 a = abuf[b % (DEPTH + 1)];
-            if constexpr (ks == 0) {
+            if constexpr (!BIAS_INIT && ks == 0) {
                 const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                acc = mfma16(a, in_frag.template operator()<ks>(), zero);
+                acc[to & 1] = mfma16(a, in_frag.template operator()<ks>(), zero);
             } else {
-                acc = mfma16(a, in_frag.template operator()<ks>(), acc);
+                acc[to & 1] = mfma16(a, in_frag.template operator()<ks>(), acc[to & 1]);
             }
-            if constexpr (ks == NKS - 1) {
-                const float* bp = bias_lds + to * 32 + h * 16;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {   // 8 registers = one B fragment of the next layer
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + 8 * half + 4 * i);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * i + e] = fmaxf(acc[8 * half + 4 * i + e] + bb[e], lo);
-#pragma unroll
-                        for (int k = 0; k < NHEAD; ++k) {
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(head_lds + k * head_stride + to * 32 + h * 16 +
-                                                                            8 * half + 4 * i);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) head[k] = fmaf(v[4 * i + e], w[e], head[k]);
-                        }
-                    }
-                    if constexpr (STORE) Y[2 * to + half] = pack8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-                    // pin the head sums here: left alone the optimiser sinks all their FMAs to the kernel's end and
-                    // keeps (spills) every fp32 activation until then
-#pragma unroll
-                    for (int k = 0; k < NHEAD; ++k) asm volatile("" : "+v"(head[k]));
-                }
+            if constexpr (to > 0) {   // the previous tile's epilogue, piece by piece, behind this tile's MFMAs
+                static_for<PPS>([&]<int Q>() {
+                    constexpr int K = ks * PPS + Q;
+                    if constexpr (K < 8) piece.template operator()<to - 1, K>();
+                });
             }
+            if constexpr (BIAS_INIT && to + 1 < NOUT && ks >= 8 && ks < 12) load_bias.template operator()<to + 1, ks - 8>();
         }
         __builtin_amdgcn_sched_barrier(0);
     });
+    static_for<8>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
 }
 
 template <bool VIEWDIRS>
