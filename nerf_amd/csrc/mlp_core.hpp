@@ -97,5 +97,56 @@ __device__ __forceinline__ void run_section(Stream& st, int lane, f32x16 (&acc)[
     });
 }
 
+// One forward layer (or one of the two sections of the skip layer) on ping-pong tile arrays:
+//     out[to] = act( start + sum_ti W(to, ti) in[ti] ),   start = bias column (bias_on) or out[to]'s current value.
+// The bias is not added afterwards: a tile's accumulator registers are loaded with its bias column from LDS while
+// the previous tile is still multiplying.  ReLU runs in place on tile to-1 behind the first MFMAs of tile to, in
+// the shadow of the matrix pipe; only the last tile's ReLU is exposed.  `bias_h` = bias table + 16 * lane half.
+// `side` is called once per output tile (side.template operator()<to>()), a few blocks into the tile: work that
+// only READS the layer's inputs (storing them for the backward pass) and so can ride in the MFMA shadow as well.
+struct NoSide {
+    template <int TO> __device__ __forceinline__ void operator()() const {}
+};
+template <int NOUT, int NIN, bool RELU, typename InTile, typename Side = NoSide>
+__device__ __forceinline__ void run_layer(Stream& st, int lane, f32x16 (&out)[8], InTile in_tile, const float* bias_h,
+                                          bool bias_on, Side side = Side{}) {
+    constexpr int NB = NOUT * NIN * 4, DEPTH = 2;
+    static_assert(NIN * 4 >= 4, "a tile spans at least four blocks");
+    f32x4 abuf[DEPTH + 1];
+    const float* cur = nullptr;
+    auto load_bias = [&]<int TO>() {
+        if (bias_on) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_h + TO * 32 + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[TO][4 * i + e] = bb[e];
+            }
+        }
+    };
+    auto relu = [&]<int TO>() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[TO][r] = fmaxf(out[TO][r], 0.0f);
+    };
+    load_bias.template operator()<0>();
+    static_for<NB + DEPTH>([&]<int I>() {
+        if constexpr (I < NB) {
+            if constexpr (I % SLAB_BLOCKS == 0) cur = st.advance(lane);
+            abuf[I % (DEPTH + 1)] = *reinterpret_cast<const f32x4*>(cur + (I % SLAB_BLOCKS) * BLOCK_FLOATS);
+        }
+        if constexpr (I >= DEPTH) {
+            constexpr int b = I - DEPTH;
+            constexpr int to = b / (NIN * 4), ti = (b >> 2) % NIN, q = b & 3;
+            const f32x4 a = abuf[b % (DEPTH + 1)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[to] = mfma(a[e], in_tile.template operator()<ti>()[4 * q + e], out[to]);
+            if constexpr (ti == NIN - 1 && q == 0 && to + 1 < NOUT) load_bias.template operator()<to + 1>();
+            if constexpr (RELU && to > 0 && ti == 0 && q == 2) relu.template operator()<to - 1>();
+            if constexpr (ti == 1 && q == 0) side.template operator()<to>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (RELU) relu.template operator()<NOUT - 1>();
+}
 
 }  // namespace nerfmlp

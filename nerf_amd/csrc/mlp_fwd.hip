@@ -7,8 +7,9 @@
 // packed stream is pulled through a two-slab LDS ring (16 KiB per slab) with global_load_lds, each
 // wave fetching a quarter of the next slab while all four consume the current one, so per
 // workgroup the whole 2.3 MiB stream is read once from L2 and every A operand is one
-// ds_read_b128 per four MFMAs.  ReLU/bias run on the VALU between layers; the 1- and 3-row heads
-// (alpha, rgb) are VALU dot products on the register-resident activations.
+// ds_read_b128 per four MFMAs.  The bias is the accumulators' initial value (loaded from LDS straight into
+// their registers), ReLU runs in place behind the next tile's MFMAs; the 1- and 3-row heads (alpha, rgb)
+// are VALU dot products on the register-resident activations.
 //
 // Bound: MFMA.  9280 MFMAs (4096 FLOP each) per 32 points = 1.188 MFLOP per point, of which
 // 1.187 MFLOP is algorithmic (the rest is zero padding of the 63/27-wide inputs).
@@ -21,41 +22,22 @@ using namespace nerfmlp;
 
 namespace {
 
-// A[t] = act(B[t] + bias)
-template <int NT, bool RELU>
-__device__ __forceinline__ void epilogue(f32x16 (&A)[8], const f32x16 (&B)[8], const float* bias_lds, int h) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float* bp = bias_lds + t * 32 + h * 16;
-        f32x16 v = B[t];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + 4 * i);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float y = v[4 * i + e] + bb[e];
-                if (RELU) y = fmaxf(y, 0.0f);
-                v[4 * i + e] = y;
-            }
-        }
-        A[t] = v;
-    }
-}
-
 // Save NT activation tiles into the blocked layout (mlp_layout.hpp).  `rows` points at the tiles' first row
 // group inside this workgroup's tile (wave-uniform), `lane_off` = half * GROUP_FLOATS + 4 * (point in tile):
 // registers 4i..4i+3 of a tile are rows 8i + 4*half + 0..3, i.e. one row group = one 16-byte store.
 // Padding points of the last tile carry the activations of the last real point: finite values that the
 // backward multiplies by exactly-zero gradients.
+template <int T>
+__device__ __forceinline__ void save_tile(const f32x16& a, float* rows, uint32_t lane_off) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+        *reinterpret_cast<f32x4*>(rows + (8 * T + 2 * i) * GROUP_FLOATS + lane_off) = v;
+    }
+}
 template <int NT>
 __device__ __forceinline__ void save_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = {A[t][4 * i], A[t][4 * i + 1], A[t][4 * i + 2], A[t][4 * i + 3]};
-            *reinterpret_cast<f32x4*>(rows + (8 * t + 2 * i) * GROUP_FLOATS + lane_off) = v;
-        }
+    static_for<NT>([&]<int T>() { save_tile<T>(A[T], rows, lane_off); });
 }
 
 // dot product of the register-resident activations (NT tiles) with a head row stored as [tile][half][16]
@@ -188,43 +170,55 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
     __syncthreads();  // aux visible; no glds in flight yet
     st.fetch(0);
 
-    f32x16 A[8], B[8];
+    // Activations ping-pong between two tile arrays: a layer reads one and accumulates into the other.
+    f32x16 P[8], Q[8];
     const uint32_t lane_off = (uint32_t)(h * GROUP_FLOATS + pw * 4);
+    const float* bias_h = aux + AUX_BIAS + h * 16;
+    auto inE = [&]<int ti>() -> const f32x16& { return E[ti]; };
+    auto inP = [&]<int ti>() -> const f32x16& { return P[ti]; };
+    auto inQ = [&]<int ti>() -> const f32x16& { return Q[ti]; };
+    auto rows = [&](int row) { return tile + (row / 4) * GROUP_FLOATS; };
 
-    // layer 0: encoded position -> B
-    run_section<8, 2, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return E[ti]; });
-    epilogue<8, true>(A, B, aux + AUX_BIAS, h);
-    if constexpr (save) save_tiles<8>(A, tile + (ACT_H0 / 4) * GROUP_FLOATS, lane_off);
+    // Training: a layer's output is stored for the backward pass while the NEXT layer, which only reads it,
+    // is multiplying (one tile's four 16-byte stores per output tile of that layer).
+    float* srows = nullptr;   // first row group of the array being stored
+    auto saveP = [&]<int TO>() { if constexpr (save) save_tile<TO>(P[TO], srows, lane_off); };
+    auto saveQ = [&]<int TO>() { if constexpr (save) save_tile<TO>(Q[TO], srows, lane_off); };
 
-    float sigma = 0.0f;
-    const int n_hidden = VIEWDIRS ? 9 : 8;  // layers 1..7, then feature_linear as "layer 8"
+    run_layer<8, 2, true>(st, lane, P, inE, bias_h, true);                       // layer 0: encoded position -> P
 #pragma unroll 1
-    for (int l = 1; l < n_hidden; ++l) {
-        run_section<8, 8, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return A[ti]; });
-        if (l == 5) run_section<8, 2, true>(st, lane, B, [&]<int ti>() -> const f32x16& { return E[ti]; });
-        const float* bias = aux + AUX_BIAS + l * 256;
-        if (l < 8) epilogue<8, true>(A, B, bias, h);
-        else epilogue<8, false>(A, B, bias, h);
-        if constexpr (save) save_tiles<8>(A, tile + ((ACT_H0 + 256 * l) / 4) * GROUP_FLOATS, lane_off);  // l == 8: ACT_FEAT
-        if (VIEWDIRS && l == 7) sigma = head_dot<8>(A, aux + AUX_HEAD, h) + aux[AUX_HEAD + 256 + 384];
+    for (int l = 1; l < 7; l += 2) {                                             // layers (1,2) (3,4) (5,6): P -> Q -> P
+        if (l == 5) run_layer<8, 2, false>(st, lane, Q, inE, bias_h + 5 * 256, true);   // skip: encoded inputs first
+        if constexpr (save) srows = rows(ACT_H0 + 256 * (l - 1));
+        run_layer<8, 8, true>(st, lane, Q, inP, bias_h + l * 256, l != 5, saveP);
+        if constexpr (save) srows = rows(ACT_H0 + 256 * l);
+        run_layer<8, 8, true>(st, lane, P, inQ, bias_h + (l + 1) * 256, true, saveQ);
     }
+    if constexpr (save) srows = rows(ACT_H0 + 256 * 6);
+    run_layer<8, 8, true>(st, lane, Q, inP, bias_h + 7 * 256, true, saveP);      // layer 7: P -> Q
 
     if (VIEWDIRS) {
-        run_section<4, 9, false>(st, lane, B, [&]<int ti>() -> const f32x16& { if constexpr (ti < 8) return A[ti]; else return D; });
-        epilogue<4, true>(A, B, aux + AUX_BIAS + 9 * 256, h);
-        if constexpr (save) save_tiles<4>(A, tile + (ACT_VIEWS / 4) * GROUP_FLOATS, lane_off);
+        const float sigma = head_dot<8>(Q, aux + AUX_HEAD, h) + aux[AUX_HEAD + 256 + 384];
+        if constexpr (save) srows = rows(ACT_H0 + 256 * 7);
+        run_layer<8, 8, false>(st, lane, P, inQ, bias_h + 8 * 256, true, saveQ); // feature_linear (no activation): Q -> P
+        if constexpr (save) srows = rows(ACT_FEAT);
+        run_layer<4, 9, true>(st, lane, Q, [&]<int ti>() -> const f32x16& { if constexpr (ti < 8) return P[ti]; else return D; },
+                              bias_h + 9 * 256, true,                            // views layer: P ++ D -> Q[0..3]
+                              [&]<int TO>() { saveP.template operator()<2 * TO>(); saveP.template operator()<2 * TO + 1>(); });
+        if constexpr (save) save_tiles<4>(Q, rows(ACT_VIEWS), lane_off);
         const float* wrgb = aux + AUX_HEAD + 256;
         const float* hb = aux + AUX_HEAD + 256 + 384;
-        const float r = head_dot<4>(A, wrgb, h) + hb[1];
-        const float g = head_dot<4>(A, wrgb + 128, h) + hb[2];
-        const float b = head_dot<4>(A, wrgb + 256, h) + hb[3];
+        const float r = head_dot<4>(Q, wrgb, h) + hb[1];
+        const float g = head_dot<4>(Q, wrgb + 128, h) + hb[2];
+        const float b = head_dot<4>(Q, wrgb + 256, h) + hb[3];
         if (valid && h == 0) {
             f32x4 o = {r, g, b, sigma};
             *reinterpret_cast<f32x4*>(out + p * 4) = o;
         }
     } else {
+        if constexpr (save) save_tiles<8>(Q, rows(ACT_H0 + 256 * 7), lane_off);
         for (int c = 0; c < output_ch; ++c) {
-            const float v = head_dot<8>(A, aux + AUX_HEAD + c * 256, h) + aux[AUX_HEAD + output_ch * 256 + c];
+            const float v = head_dot<8>(Q, aux + AUX_HEAD + c * 256, h) + aux[AUX_HEAD + output_ch * 256 + c];
             if (valid && h == 0) out[p * output_ch + c] = v;
         }
     }

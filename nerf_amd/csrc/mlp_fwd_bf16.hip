@@ -303,7 +303,8 @@ __global__ void __launch_bounds__(256) k_pack_bf16(int use_viewdirs, const float
                 int64_t fb = 2 * b + (j >> 2);           // two fp32 blocks (4 registers each) make one bf16 block
                 if (b >= 544 && b < 704) {               // layer 5: per output tile, hidden k-steps then encoded ones
                     const int lb = (int)b - 544, to = lb / 20, ks = lb % 20;
-                    fb = ks < 16 ? 1088 + to * 32 + 2 * ks + (j >> 2) : 1344 + to * 8 + 2 * (ks - 16) + (j >> 2);
+                    // fp32 stream: encoded-input part at blocks 1088..1151 (8 per tile), hidden part at 1152..1407 (32 per tile)
+                    fb = ks < 16 ? 1152 + to * 32 + 2 * ks + (j >> 2) : 1088 + to * 8 + 2 * (ks - 16) + (j >> 2);
                 }
                 v = packed_fwd[fb * BLOCK_FLOATS + lane * 4 + (j & 3)];
             }

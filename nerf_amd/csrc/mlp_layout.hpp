@@ -92,9 +92,9 @@ NL_HD inline ParamOffsets param_offsets(int use_viewdirs, int output_ch) {
 }
 
 // ---- forward stream ------------------------------------------------------------------------------
-// sections, in consumption order (blocks): L0 [64] | L1..L4 [256 each] | L5 hidden part [256] |
-// L5 encoded-input part [64] | L6, L7 [256 each] | (view branch) feature [256] | views [144]
-constexpr int FWD_SEC_L0 = 0, FWD_SEC_L5E = 6, FWD_SEC_FEAT = 9, FWD_SEC_VIEWS = 10;
+// sections, in consumption order (blocks): L0 [64] | L1..L4 [256 each] | L5 encoded-input part [64] |
+// L5 hidden part [256] | L6, L7 [256 each] | (view branch) feature [256] | views [144]
+constexpr int FWD_SEC_L0 = 0, FWD_SEC_L5E = 5, FWD_SEC_L5H = 6, FWD_SEC_FEAT = 9, FWD_SEC_VIEWS = 10;
 NL_HD inline int fwd_section_blocks(int sec) {
     if (sec == FWD_SEC_L0 || sec == FWD_SEC_L5E) return 64;
     if (sec == FWD_SEC_VIEWS) return 144;
@@ -150,7 +150,7 @@ NL_HD inline int64_t fwd_source(int use_viewdirs, int output_ch, int64_t idx) {
         const int ti = (int)((blk >> 2) % 8), to = (int)(blk >> 5);
         const int row = 32 * to + row32, col = tile_feature(ti, r, h);
         if (sec == FWD_SEC_FEAT) return po.feat_w + (int64_t)row * W + col;
-        if (sec == 5) return po.pts_w[5] + (int64_t)row * (W + IN_PTS) + IN_PTS + col;
+        if (sec == FWD_SEC_L5H) return po.pts_w[5] + (int64_t)row * (W + IN_PTS) + IN_PTS + col;
         const int layer = sec <= 4 ? sec : sec - 1;              // sections 7,8 are layers 6,7
         return po.pts_w[layer] + (int64_t)row * W + col;
     }
