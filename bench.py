@@ -14,7 +14,8 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                 mean launch duration measured with HIP events on the launch stream, against the
                 fp32 matrix peak of MI355X;
   cpu_baseline: the CPU oracle (a PyTorch-CPU restatement of the reference path, proven equal to
-                the reference on the golden fixtures) timed on this host on a bounded ray sample;
+                the reference on the golden fixtures) timed on this host on a bounded ray sample -- the
+                only place this file touches oracle/;
   train:        (when the backward is available) one lego train step, rays/s.
 """
 import argparse
@@ -43,17 +44,37 @@ def lego_camera(H, W):
     return np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
 
 
+def synthetic_weights(model, seed):
+    """Random-init weights of the benchmark networks: U(+-1/sqrt(fan_in)) per layer from a portable PCG64 stream,
+    with the density head scaled up (a random init is almost transparent; give the rays something to hit)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for name, p in model.state_dict().items():
+        if not name.endswith(".weight"):
+            continue
+        n_out, n_in = p.shape
+        b = 1.0 / np.sqrt(n_in)
+        sd[name] = torch.from_numpy(rng.uniform(-b, b, size=(n_out, n_in)).astype(np.float32))
+        sd[name[:-6] + "bias"] = torch.from_numpy(rng.uniform(-b, b, size=(n_out,)).astype(np.float32))
+    sd["alpha_linear.weight"] *= 30.0
+    sd["alpha_linear.bias"] += 0.3
+    return sd
+
+
+def orbit_pose(theta_deg):
+    """Camera-to-world [3,4] of the lego test orbit (elevation -30 degrees, radius 4)."""
+    from nerf_amd.datasets import pose_spherical
+    return pose_spherical(float(theta_deg), -30.0, 4.0)[:3, :4]
+
+
 def build_scene(dev, seed=0):
     from nerf_amd.run_nerf import run_network
     from nerf_amd.run_nerf_helpers import NeRF, get_embedder
-    from oracle import nerf_oracle as O
     sds = []
     models = []
     for s in (seed, seed + 1):
-        sd = O.random_state_dict(s)
-        sd["alpha_linear.weight"] *= 30.0          # random init is almost transparent; give the rays something to hit
-        sd["alpha_linear.bias"] += 0.3
         m = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        sd = synthetic_weights(m, s)
         m.load_state_dict(sd)
         models.append(m.to(dev))
         sds.append(sd)
@@ -92,7 +113,7 @@ def cpu_train_baseline(sds, n_rand, steps):
     pf = {k: v.clone().requires_grad_(True) for k, v in sds[1].items()}
     params = list(pc.values()) + list(pf.values())
     opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
-    o, d = O.pixel_rays(H, W, K, O.orbit_pose(30.0, -30.0, 4.0)[:3, :4])
+    o, d = O.pixel_rays(H, W, K, orbit_pose(30.0))
     times = []
     for i in range(steps + 1):
         t0 = time.perf_counter()
@@ -132,7 +153,6 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
     from nerf_amd import ops, parallel
     from nerf_amd.run_nerf import render
     from nerf_amd.run_nerf_helpers import get_rays, img2mse
-    from oracle import nerf_oracle as O
     H = W = 400
     K = lego_camera(H, W)
     kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
@@ -142,7 +162,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     thetas = np.linspace(-180, 180, 41)[:-1]
-    poses = [O.orbit_pose(float(thetas[i % 40]), -30.0, 4.0)[:3, :4].to(dev) for i in range(warmup + steps)]
+    poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(warmup + steps)]
     target_img = torch.rand(H * W, 3, device=dev, generator=gen)
 
     def one(i):
@@ -216,14 +236,13 @@ def main():
 
     from nerf_amd import ops
     from nerf_amd.run_nerf import render
-    from oracle import nerf_oracle as O
 
     H = W = args.res
     K = lego_camera(H, W)
     models, sds, kwargs = build_scene(dev)
     thetas = np.linspace(-180, 180, 40 + 1)[:-1]
     n_views = args.warmup + args.steps
-    poses = [O.orbit_pose(float(thetas[(rank * n_views + i) % 40]), -30.0, 4.0)[:3, :4].to(dev) for i in range(n_views)]
+    poses = [orbit_pose(thetas[(rank * n_views + i) % 40]).to(dev) for i in range(n_views)]
     chunk = 1024 * 32
 
     def step(i):
