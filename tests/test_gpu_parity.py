@@ -389,6 +389,37 @@ def test_render_whole_image_and_chunk_independence(device):
     exact(disp, disp2, "chunk size (disp)")
 
 
+def test_full_size_chunks_are_independent_and_match_the_oracle(device):
+    """At the benchmark's chunk size (32768 rays x 64+128 samples) and at the stress shape (256+512 samples, chunk
+    65536): a deterministic render does not depend on how the rays are chunked (bit for bit), and a random subset of
+    its rays matches the oracle."""
+    from nerf_amd.run_nerf import render
+    sd_c, sd_f = _peaky(O.random_state_dict(31), 40.0), _peaky(O.random_state_dict(32), 60.0)
+    mc, mf = _model(sd_c, device), _model(sd_f, device)
+    qf = _query_fn()
+    rng = np.random.Generator(np.random.PCG64(21))
+    H = W = 400
+    K = np.array([[555.5555, 0, 200.0], [0, 555.5555, 200.0], [0, 0, 1]])
+    o, d = O.pixel_rays(H, W, K, O.orbit_pose(77.0, -30.0, 4.0)[:3, :4])
+    for n, sc, si, big, small in ((40000, 64, 128, 1 << 15, 4096), (3000, 256, 512, 1 << 16, 1000)):
+        pick = torch.from_numpy(rng.choice(H * W, size=n, replace=False))
+        rays = torch.stack([o.reshape(-1, 3)[pick], d.reshape(-1, 3)[pick]], 0)
+        kw = dict(network_fn=mc, network_query_fn=qf, N_samples=sc, N_importance=si, network_fine=mf, perturb=0.0,
+                  white_bkgd=True, use_viewdirs=True, ndc=False, near=2.0, far=6.0)
+        with torch.no_grad():
+            a = render(H, W, K, chunk=big, rays=rays.to(device), **kw)
+            b = render(H, W, K, chunk=small, rays=rays.to(device), **kw)
+        for x, y, what in zip(a[:3], b[:3], ("rgb", "disp", "acc")):
+            exact(x, y, f"{what}: chunk {big} vs {small} at {sc}+{si}")
+        exact(a[3]["z_std"], b[3]["z_std"], "z_std chunking")
+        sub = torch.from_numpy(rng.choice(n, size=96, replace=False))
+        with torch.no_grad():
+            want = O.render_chunks(O.pack_rays(rays[0][sub], rays[1][sub], 2.0, 6.0, use_viewdirs=True), 1 << 15, sd_coarse=sd_c,
+                                   sd_fine=sd_f, n_coarse=sc, n_fine=si, white_bkgd=True)
+        close(a[0][sub.to(device)], want["rgb_map"], 2e-4, 2e-5, f"rgb vs oracle at {sc}+{si}")
+        close(a[2][sub.to(device)], want["acc_map"], 2e-4, 2e-5, f"acc vs oracle at {sc}+{si}")
+
+
 # ---------------------------------------------------------------------------------------------
 # gradients
 # ---------------------------------------------------------------------------------------------
