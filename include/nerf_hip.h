@@ -154,11 +154,12 @@ int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int ou
                          const float* packed_fwd, float* out, float* act, void* stream);
 
 /* bf16-operand / fp32-accumulate inference variant of nerf_mlp_fwd (same arguments and outputs).
- * packed_bf16: nerf_mlp_packed_bf16_bytes() bytes built by nerf_pack_weights_bf16 from the fp32
- * forward stream.  Every product's inputs are rounded to bf16 (8 significant bits), sums and heads
- * are fp32: raw outputs agree with the fp32 path to about 1e-2 of their scale. */
+ * packed_bf16: nerf_mlp_packed_bf16_bytes() bytes built by nerf_pack_weights_bf16 from the flat
+ * parameter vector (the module's parameters concatenated in state_dict order, as for nerf_pack_weights).
+ * Every product's inputs are rounded to bf16 (8 significant bits), sums and heads are fp32: raw outputs
+ * agree with the fp32 path to about 1e-2 of their scale. */
 int64_t nerf_mlp_packed_bf16_bytes(int use_viewdirs);
-int nerf_pack_weights_bf16(int use_viewdirs, const float* packed_fwd, void* packed_bf16, void* stream);
+int nerf_pack_weights_bf16(int use_viewdirs, int output_ch, const float* params, void* packed_bf16, void* stream);
 int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                       int use_viewdirs, int output_ch, const void* packed_bf16, float* out, void* stream);
 

@@ -1,18 +1,20 @@
 // Fused positional encoding + NeRF MLP forward, bf16 operands / fp32 accumulation (inference variant).
 //
-// Same dataflow as the fp32 kernel (mlp_fwd.hip): activations stay in registers from the encoding to
-// the heads, weights stream through an LDS slab ring.  Differences that follow from the 16x faster
-// v_mfma_f32_32x32x16_bf16:
-//   * a workgroup is EIGHT waves (256 points), two per SIMD, each under 256 registers: while one wave of a
-//     SIMD runs its VALU epilogue (bias, ReLU, bf16 rounding) the other keeps the matrix pipe busy, and
-//     the L2 -> LDS weight traffic per point is half that of a four-wave group;
-//   * after ReLU (fp32, VALU; the bias is the accumulator's initial value) the accumulators are rounded to bf16
-//     and packed pairwise, in the shadow of the next tile's MFMAs; registers
-//     8s..8s+7 of an accumulator tile are exactly the B fragment of k-step s of the next layer
-//     (k = 16s + 8(j>>2) + 4*half + (j&3)), so again no data leaves the register file.  The stream is
-//     the fp32 stream re-blocked (two fp32 blocks -> one 1 KiB block of 64 lanes x 8 bf16);
-//   * the 1- and 3-row heads read the fp32 accumulators (before rounding), the encodings are computed
-//     in fp32 and rounded once.
+// Same dataflow as the fp32 kernel (mlp_fwd.hip): activations stay in registers from the encoding to the
+// heads, weights stream through an LDS slab ring.  Built on v_mfma_f32_16x16x32_bf16, the bf16 shape that
+// holds the highest clock under load on this chip:
+//   * a wave carries 32 points as TWO 16-point column tiles that share every A (weight) fragment; a
+//     workgroup is eight waves (256 points), two per SIMD, each under 256 registers;
+//   * an output tile is 16 features x 16 points, 4 fp32 per lane: lane l = (point l&15, group g = l>>4)
+//     holds features 16t + 4g + r.  Two consecutive row tiles (2s, 2s+1) therefore give a lane 8 values,
+//     exactly one B fragment of k-step s of the next layer if k-slot j of group g stands for feature
+//     32s + kslot_feature(g, j); the weight stream is packed in that k order, so rounding to bf16 and
+//     packing pairwise is all that happens between layers.  No data leaves the register file;
+//   * the bias is the accumulators' initial value (LDS -> accumulator registers while the previous tile is
+//     multiplying) and the ReLU / rounding / packing of a tile is issued piecewise behind the first MFMAs
+//     of the next tile; the 1- and 3-row heads are fp32 FMAs on the unrounded accumulators;
+//   * the encodings are computed in fp32 and rounded once; each of the four lane groups of a point
+//     evaluates a quarter of the sin/cos pairs.
 // Numerics: inputs of every product are rounded to 8 significant bits, sums are fp32.  Against the
 // fp32 path the raw outputs differ by about 1e-2 of their scale (tolerance stated in the tests).
 #include "common.hpp"
@@ -25,24 +27,112 @@ using namespace nerfmlp;
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int NCOL = 1;                       // 32-point column tiles per wave
 constexpr int THREADS16 = 512;                // eight waves, two per SIMD
-constexpr int WG_PTS = (THREADS16 / 64) * 32 * NCOL;  // points per workgroup
+constexpr int WG_PTS = (THREADS16 / 64) * 32; // points per workgroup
 constexpr int SLAB16 = 32;                    // 1 KiB blocks per slab
 constexpr int SLAB16_BYTES = SLAB16 * 1024;
 constexpr int RING16_BYTES = 2 * SLAB16_BYTES;
 
-__host__ __device__ inline int bf16_stream_blocks(int use_viewdirs) { return fwd_stream_blocks(use_viewdirs) / 2; }
+// ---- stream layout ------------------------------------------------------------------------------
+// Block = one A fragment of v_mfma_f32_16x16x32_bf16: [64 lanes][8 bf16]; lane l, element j holds
+// W[row 16*to + (l&15)][input feature of k-step ks, group l>>4, slot j].  Blocks are ordered row tile by
+// row tile, a tile's k-steps consecutively.  Sections (blocks):
+//   L0 32 (16 tiles x 2 k-steps of encoded position) | L1..L4 128 each | L5 160 (per tile: 8 hidden + 2 encoded) |
+//   L6, L7 128 | feature 128 | views 72 (8 tiles x (8 feature + 1 encoded direction)); every section starts on a slab.
+__host__ __device__ inline int bf16_stream_blocks(int use_viewdirs) { return use_viewdirs ? 1160 : 960; }
 __host__ __device__ inline int bf16_stream_slabs(int use_viewdirs) { return (bf16_stream_blocks(use_viewdirs) + SLAB16 - 1) / SLAB16; }
-__host__ __device__ inline int64_t bf16_packed_bytes(int use_viewdirs) {
-    return (int64_t)bf16_stream_slabs(use_viewdirs) * SLAB16_BYTES + (int64_t)AUX_FLOATS * 4;
+
+// feature (inside a 32-feature k-step) that k-slot j of lane group g stands for
+__host__ __device__ inline int kslot_feature(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); }
+
+// Encoded position: 64 slots per point = 2 k-steps x 4 groups x 8; group g evaluates the (frequency, axis) pairs
+// c0(g) .. c0(g)+np(g)-1 (8, 8, 7, 7 of the 30) and keeps sin and cos side by side; the raw coordinates fill
+// the last slots of groups 2 and 3.  -> encoded feature index (run_nerf_helpers.py:13-66 order), or -1 (padding).
+__host__ __device__ inline int enc16_first_pair(int g) { return g < 2 ? 8 * g : 16 + 7 * (g - 2); }
+__host__ __device__ inline int enc16_pts_feature(int ks, int g, int j) {
+    const int q = 8 * ks + j, i = q >> 1, np = g < 2 ? 8 : 7;
+    if (i < np) {
+        const int c = enc16_first_pair(g) + i, k = c / 3, d = c % 3;
+        return 3 + 6 * k + 3 * (q & 1) + d;
+    }
+    if (g == 2) return q - 14;            // x, y
+    return q == 14 ? 2 : -1;              // z, padding
+}
+// Encoded direction: 32 slots = 4 groups x 8; group g evaluates pairs 3g .. 3g+2, raw components in slots 6, 7.
+__host__ __device__ inline int enc16_dirs_feature(int g, int j) {
+    if (j < 6) {
+        const int c = 3 * g + (j >> 1), k = c / 3, d = c % 3;
+        return 3 + 6 * k + 3 * (j & 1) + d;
+    }
+    if (g == 0) return j - 6;             // x, y
+    return (g == 1 && j == 6) ? 2 : -1;   // z
 }
 
+// aux tables behind the stream (floats, natural feature order), copied to LDS once per workgroup:
+//   bias[10][256] (layers 0..7, feature, views (128 used)); view branch: alpha[256], rgb[3][128], alpha_b, rgb_b[3];
+//   otherwise output_linear[8][256], out_b[8]
+constexpr int AUX16_BIAS = 0, AUX16_HEAD = 10 * 256, AUX16_FLOATS = AUX16_HEAD + 8 * 256 + 8;
+__host__ __device__ inline int64_t bf16_packed_bytes(int use_viewdirs) {
+    return (int64_t)bf16_stream_slabs(use_viewdirs) * SLAB16_BYTES + (int64_t)AUX16_FLOATS * 4;
+}
+
+// flat-parameter index of stream element (block, lane, j), or -1 for zero padding
+__host__ __device__ inline int64_t bf16_stream_source(int use_viewdirs, int output_ch, int blk, int lane, int j) {
+    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
+    const int r16 = lane & 15, g = lane >> 4;
+    if (blk < 32) {
+        const int f = enc16_pts_feature(blk & 1, g, j);
+        return f < 0 ? -1 : po.pts_w[0] + (int64_t)(16 * (blk >> 1) + r16) * IN_PTS + f;
+    }
+    blk -= 32;
+    for (int l = 1; l < 8; ++l) {
+        const int n = (l == 5) ? 160 : 128;
+        if (blk < n) {
+            const int per = (l == 5) ? 10 : 8, row = 16 * (blk / per) + r16, ks = blk % per;
+            const int ld = (l == 5) ? W + IN_PTS : W;
+            if (ks < 8) return po.pts_w[l] + (int64_t)row * ld + (l == 5 ? IN_PTS : 0) + 32 * ks + kslot_feature(g, j);
+            const int f = enc16_pts_feature(ks - 8, g, j);
+            return f < 0 ? -1 : po.pts_w[5] + (int64_t)row * ld + f;
+        }
+        blk -= n;
+    }
+    if (!use_viewdirs) return -1;
+    if (blk < 128) return po.feat_w + (int64_t)(16 * (blk >> 3) + r16) * W + 32 * (blk & 7) + kslot_feature(g, j);
+    blk -= 128;
+    const int row = 16 * (blk / 9) + r16, ks = blk % 9;
+    if (ks < 8) return po.views_w + (int64_t)row * po.views_in + 32 * ks + kslot_feature(g, j);
+    const int f = enc16_dirs_feature(g, j);
+    return f < 0 ? -1 : po.views_w + (int64_t)row * po.views_in + W + f;
+}
+
+__host__ __device__ inline int64_t bf16_aux_source(int use_viewdirs, int output_ch, int a) {
+    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
+    if (a < AUX16_HEAD) {
+        const int layer = a >> 8, f = a & 255;
+        if (layer < 8) return po.pts_b[layer] + f;
+        if (!use_viewdirs) return -1;
+        if (layer == 8) return po.feat_b + f;
+        return f < W / 2 ? po.views_b + f : -1;
+    }
+    a -= AUX16_HEAD;
+    if (use_viewdirs) {
+        if (a < 256) return po.alpha_w + a;
+        a -= 256;
+        if (a < 384) return po.rgb_w + a;
+        a -= 384;
+        if (a == 0) return po.alpha_b;
+        return a < 4 ? po.rgb_b + (a - 1) : -1;
+    }
+    if (a < 8 * 256) return (a >> 8) < output_ch ? po.out_w + a : -1;
+    a -= 8 * 256;
+    return a < output_ch ? po.out_b + a : -1;
+}
+
+// ---- the slab ring as one wave sees it ----------------------------------------------------------
 struct Stream16 {
-    const char* g;   // this lane's source for block 8*wave of slab 0
+    const char* g;   // this lane's source for block 4*wave of slab 0
     char* ring;
     char* mine;
     int next, nslabs;
@@ -63,48 +153,45 @@ struct Stream16 {
     }
 };
 
-__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
     bf16x8 r;
-    r[0] = (__bf16)v0; r[1] = (__bf16)v1; r[2] = (__bf16)v2; r[3] = (__bf16)v3;
-    r[4] = (__bf16)v4; r[5] = (__bf16)v5; r[6] = (__bf16)v6; r[7] = (__bf16)v7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
     return r;
 }
 
-// One layer: for every 32-row output tile, NKS MFMAs (k-steps of 16) on the input fragments, then the tile's
-// epilogue on the VALU: y = max(acc, lo) (lo = 0: ReLU, -inf: none), optional head rows as fp32 dot products
-// with y, and y rounded to bf16 into the two B fragments the next layer reads (Y[2*to], Y[2*to+1]).
-// Two accumulator tiles alternate, and the epilogue is cut into eight pieces (two registers -> one packed
-// dword each) issued one per k-step behind the first eight MFMAs of the NEXT tile, so it runs in the shadow
-// of the matrix pipe instead of stalling it; only a layer's last tile is finished in the open.  The bias is
-// not added afterwards: an accumulator starts as the tile's bias column, read from LDS straight into its
-// registers while the previous tile is still multiplying (layers with at least 12 k-steps; the 4-step first
-// layer adds it in the epilogue).  Weight blocks are read DEPTH ahead, also across tiles and slab barriers.
-// Every layer starts on a slab boundary.
+// One layer: NOUT row tiles (16 features each) x NKS k-steps (32 input features each) x 2 column tiles.
+// Two accumulator sets alternate; the epilogue of row tile t -- y = max(acc, lo) (lo = 0: ReLU, -inf: none), head
+// rows as fp32 dot products with y, y rounded to bf16 into slots 4(t%2)..+3 of fragment t/2 of both column tiles --
+// is cut into four pieces (two registers -> one packed dword) issued one per k-step behind the first MFMAs of
+// row tile t+1.  Layers with at least seven k-steps start each accumulator as the tile's bias column; the two-step
+// first layer adds the bias in the epilogue.  Blocks are read DEPTH ahead, also across tiles and slab barriers.
 template <int NOUT, int NKS, int NHEAD, bool STORE, typename InFrag>
-__device__ __forceinline__ void layer16(Stream16& st, int lane, int h, const char*& cur, InFrag in_frag, bf16x8 (&Y)[16],
+__device__ __forceinline__ void layer16(Stream16& st, int lane, int g, const char*& cur, InFrag in_frag, bf16x8 (&Y)[2][8],
                                         const float* bias_lds, float lo, const float* head_lds, int head_stride,
-                                        float (&head)[3]) {
+                                        float (&head)[2][3]) {
     constexpr int NB = NOUT * NKS, DEPTH = 3;
-    constexpr bool BIAS_INIT = NKS >= 12;
-    constexpr int PPS = NKS >= 8 ? 1 : 8 / NKS;   // epilogue pieces per k-step
+    constexpr bool BIAS_INIT = NKS >= 7;
+    constexpr int PPS = NKS >= 4 ? 1 : 4 / NKS;   // epilogue pieces per k-step
     bf16x8 abuf[DEPTH + 1];
-    f32x16 acc[2];
-    const float* bp = bias_lds + h * 16;
-    const float* hp = head_lds + h * 16;
+    f32x4 acc[2][2];                              // [alternating set][column tile]
+    const float* bp = bias_lds + 4 * g;
+    const float* hp = head_lds + 4 * g;
 
-    auto load_bias = [&]<int TO, int Q>() {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + TO * 32 + 4 * Q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[TO & 1][4 * Q + e] = bb[e];
+    auto load_bias = [&]<int TO>() {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + 16 * TO);
+        acc[TO & 1][0] = bb;
+        acc[TO & 1][1] = bb;
     };
-    auto piece = [&]<int TP, int K>() {
-        float v0 = acc[TP & 1][2 * K], v1 = acc[TP & 1][2 * K + 1];
+    auto piece = [&]<int TP, int K>() {           // K = 2 * column tile + register pair
+        constexpr int ct = K >> 1, pr = K & 1;
+        float v0 = acc[TP & 1][ct][2 * pr], v1 = acc[TP & 1][ct][2 * pr + 1];
         if constexpr (!BIAS_INIT) {
-            const f32x2 bb = *reinterpret_cast<const f32x2*>(bp + TP * 32 + 2 * K);
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(bp + 16 * TP + 2 * pr);
             v0 += bb[0];
             v1 += bb[1];
         }
@@ -112,19 +199,19 @@ __device__ __forceinline__ void layer16(Stream16& st, int lane, int h, const cha
         v1 = fmaxf(v1, lo);
 #pragma unroll
         for (int k = 0; k < NHEAD; ++k) {
-            const f32x2 w = *reinterpret_cast<const f32x2*>(hp + k * head_stride + TP * 32 + 2 * K);
-            head[k] = fmaf(v1, w[1], fmaf(v0, w[0], head[k]));
-            // pin the head sums here: left alone the optimiser sinks all their FMAs to the kernel's end and keeps
-            // (spills) every fp32 activation until then
-            asm volatile("" : "+v"(head[k]));
+            const f32x2 w = *reinterpret_cast<const f32x2*>(hp + k * head_stride + 16 * TP + 2 * pr);
+            head[ct][k] = fmaf(v1, w[1], fmaf(v0, w[0], head[ct][k]));
+            // pin the head sums here: left alone the optimiser sinks their FMAs to the kernel's end and keeps every
+            // fp32 activation alive until then
+            asm volatile("" : "+v"(head[ct][k]));
         }
         if constexpr (STORE) {
-            Y[2 * TP + (K >> 2)][2 * (K & 3)] = (__bf16)v0;
-            Y[2 * TP + (K >> 2)][2 * (K & 3) + 1] = (__bf16)v1;
+            Y[ct][TP >> 1][4 * (TP & 1) + 2 * pr] = (__bf16)v0;
+            Y[ct][TP >> 1][4 * (TP & 1) + 2 * pr + 1] = (__bf16)v1;
         }
     };
 
-    if constexpr (BIAS_INIT) static_for<4>([&]<int Q>() { load_bias.template operator()<0, Q>(); });
+    if constexpr (BIAS_INIT) load_bias.template operator()<0>();
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
             if constexpr (I % SLAB16 == 0) cur = st.advance(lane);
@@ -135,22 +222,24 @@ __device__ __forceinline__ void layer16(Stream16& st, int lane, int h, const cha
             constexpr int to = b / NKS, ks = b % NKS;
             const bf16x8 a = abuf[b % (DEPTH + 1)];
             if constexpr (!BIAS_INIT && ks == 0) {
-                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                acc[to & 1] = mfma16(a, in_frag.template operator()<ks>(), zero);
+                const f32x4 zero = {0, 0, 0, 0};
+                acc[to & 1][0] = mfma16(a, in_frag.template operator()<0, ks>(), zero);
+                acc[to & 1][1] = mfma16(a, in_frag.template operator()<1, ks>(), zero);
             } else {
-                acc[to & 1] = mfma16(a, in_frag.template operator()<ks>(), acc[to & 1]);
+                acc[to & 1][0] = mfma16(a, in_frag.template operator()<0, ks>(), acc[to & 1][0]);
+                acc[to & 1][1] = mfma16(a, in_frag.template operator()<1, ks>(), acc[to & 1][1]);
             }
-            if constexpr (to > 0) {   // the previous tile's epilogue, piece by piece, behind this tile's MFMAs
+            if constexpr (to > 0) {   // the previous row tile's epilogue, piece by piece, behind this tile's MFMAs
                 static_for<PPS>([&]<int Q>() {
                     constexpr int K = ks * PPS + Q;
-                    if constexpr (K < 8) piece.template operator()<to - 1, K>();
+                    if constexpr (K < 4) piece.template operator()<to - 1, K>();
                 });
             }
-            if constexpr (BIAS_INIT && to + 1 < NOUT && ks >= 8 && ks < 12) load_bias.template operator()<to + 1, ks - 8>();
+            if constexpr (BIAS_INIT && to + 1 < NOUT && ks == NKS - 3) load_bias.template operator()<to + 1>();
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    static_for<8>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
+    static_for<4>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
 }
 
 template <bool VIEWDIRS>
@@ -160,60 +249,50 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     char* ring = smem16;
     float* aux = reinterpret_cast<float*>(smem16 + RING16_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     constexpr int UV = VIEWDIRS ? 1 : 0;
     {
         const float* gaux = reinterpret_cast<const float*>(packed + (int64_t)bf16_stream_slabs(UV) * SLAB16_BYTES);
-        for (int i = tid * 4; i < AUX_FLOATS; i += THREADS16 * 4)
+        for (int i = tid * 4; i < AUX16_FLOATS; i += THREADS16 * 4)
             *reinterpret_cast<f32x4*>(aux + i) = *reinterpret_cast<const f32x4*>(gaux + i);
     }
 
-    int64_t p[NCOL];
-    bool valid[NCOL];
-    bf16x8 E[NCOL][4], D[NCOL][2];
+    // ---- encodings: this lane's group evaluates its share of the sin/cos pairs for its two points
+    bf16x8* ed = reinterpret_cast<bf16x8*>(smem16 + RING16_BYTES + AUX16_FLOATS * 4) + wave * (6 * 64) + lane;
+    int64_t p[2];
+    bool valid[2];
+    const int c0 = enc16_first_pair(g);
 #pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        p[c] = (int64_t)blockIdx.x * WG_PTS + wave * (32 * NCOL) + c * 32 + (lane & 31);
-        valid[c] = p[c] < n_pts;
-        const int64_t pl = valid[c] ? p[c] : n_pts - 1;
-        float e[32];
+    for (int ct = 0; ct < 2; ++ct) {
+        p[ct] = (int64_t)blockIdx.x * WG_PTS + wave * 32 + ct * 16 + (lane & 15);
+        valid[ct] = p[ct] < n_pts;
+        const int64_t pl = valid[ct] ? p[ct] : n_pts - 1;
         const float x0 = pts[pl * 3 + 0], x1 = pts[pl * 3 + 1], x2 = pts[pl * 3 + 2];
-        e[0] = h ? x2 : x0;
-        e[1] = h ? 0.0f : x1;
+        float e[16];
 #pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            const int cc = 15 * h + i, k = cc / 3, d = cc - 3 * k;
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i, k = c / 3, d = c - 3 * k;   // (groups 2, 3: pair 7 is overwritten below)
             const float arg = (d == 0 ? x0 : (d == 1 ? x1 : x2)) * __int_as_float((127 + k) << 23);
-            sincosf(arg, &e[2 + 2 * i], &e[3 + 2 * i]);
+            sincosf(arg, &e[2 * i], &e[2 * i + 1]);
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            E[c][s] = pack8(e[8 * s], e[8 * s + 1], e[8 * s + 2], e[8 * s + 3], e[8 * s + 4], e[8 * s + 5], e[8 * s + 6], e[8 * s + 7]);
+        if (g == 2) { e[14] = x0; e[15] = x1; }
+        if (g == 3) { e[14] = x2; e[15] = 0.0f; }
+        ed[(2 * ct + 0) * 64] = pack8(e);
+        ed[(2 * ct + 1) * 64] = pack8(e + 8);
         if (VIEWDIRS) {
             const int64_t ray = pl / pts_per_ray;
             const float v0 = viewdirs[ray * 3 + 0], v1 = viewdirs[ray * 3 + 1], v2 = viewdirs[ray * 3 + 2];
-            float dd[16];
-            dd[0] = h ? v2 : v0;
-            dd[1] = h ? 0.0f : v1;
+            float dd[8];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int cc = 6 * h + i, k = cc / 3, d = cc - 3 * k;
+            for (int i = 0; i < 3; ++i) {
+                const int c = 3 * g + i, k = c / 3, d = c - 3 * k;
                 const float arg = (d == 0 ? v0 : (d == 1 ? v1 : v2)) * __int_as_float((127 + k) << 23);
-                sincosf(arg, &dd[2 + 2 * i], &dd[3 + 2 * i]);
+                sincosf(arg, &dd[2 * i], &dd[2 * i + 1]);
             }
-            dd[14] = 0.0f;
-            dd[15] = 0.0f;
-            D[c][0] = pack8(dd[0], dd[1], dd[2], dd[3], dd[4], dd[5], dd[6], dd[7]);
-            D[c][1] = pack8(dd[8], dd[9], dd[10], dd[11], dd[12], dd[13], dd[14], dd[15]);
+            dd[6] = g == 0 ? v0 : (g == 1 ? v2 : 0.0f);
+            dd[7] = g == 0 ? v1 : 0.0f;
+            ed[(4 + ct) * 64] = pack8(dd);
         }
-    }
-
-    bf16x8* ed = reinterpret_cast<bf16x8*>(smem16 + RING16_BYTES + AUX_FLOATS * 4) + wave * (6 * 64) + lane;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ed[k * 64] = E[0][k];
-    if (VIEWDIRS) {
-        ed[4 * 64] = D[0][0];
-        ed[5 * 64] = D[0][1];
     }
 
     Stream16 st;
@@ -226,97 +305,87 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
     st.fetch(0);
     const char* cur = nullptr;
 
-    bf16x8 X[16], Y[16];
-    float sig[3] = {0.0f, 0.0f, 0.0f}, rgb[3] = {0.0f, 0.0f, 0.0f};
+    bf16x8 X[2][8], Y[2][8];
+    float sig[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, rgb[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
     const float NOCLAMP = -__builtin_inff();
-    const float* bias = aux + AUX_BIAS;
+    const float* bias = aux + AUX16_BIAS;
+    const float* hw = aux + AUX16_HEAD;
     // the encodings wait in LDS (6 fragments per lane) so that two waves per SIMD fit the register file
-    auto fromE = [&]<int ks>() -> bf16x8 { return ed[ks * 64]; };
-    auto fromX = [&]<int ks>() -> bf16x8 { return X[ks]; };
-    auto fromY = [&]<int ks>() -> bf16x8 { return Y[ks]; };
-    auto fromXE = [&]<int ks>() -> bf16x8 { if constexpr (ks < 16) return X[ks]; else return ed[(ks - 16) * 64]; };
-    auto fromXD = [&]<int ks>() -> bf16x8 { if constexpr (ks < 16) return X[ks]; else return ed[(4 + ks - 16) * 64]; };
+    auto fromE = [&]<int ct, int ks>() -> bf16x8 { return ed[(2 * ct + ks) * 64]; };
+    auto fromX = [&]<int ct, int ks>() -> bf16x8 { return X[ct][ks]; };
+    auto fromY = [&]<int ct, int ks>() -> bf16x8 { return Y[ct][ks]; };
+    auto fromXE = [&]<int ct, int ks>() -> bf16x8 { if constexpr (ks < 8) return X[ct][ks]; else return ed[(2 * ct + ks - 8) * 64]; };
+    auto fromXD = [&]<int ct, int ks>() -> bf16x8 { if constexpr (ks < 8) return X[ct][ks]; else return ed[(4 + ct) * 64]; };
 
-    // stream (1 KiB blocks): L0 32 | L1..L4 128 each | L5 160 (per tile: 16 hidden + 4 encoded k-steps) |
-    //                        L6, L7 128 | feature 128 | views 72
-    layer16<8, 4, 0, true>(st, lane, h, cur, fromE, X, bias, 0.0f, aux, 0, sig);                    // L0
-    layer16<8, 16, 0, true>(st, lane, h, cur, fromX, Y, bias + 1 * 256, 0.0f, aux, 0, sig);         // L1
-    layer16<8, 16, 0, true>(st, lane, h, cur, fromY, X, bias + 2 * 256, 0.0f, aux, 0, sig);         // L2
-    layer16<8, 16, 0, true>(st, lane, h, cur, fromX, Y, bias + 3 * 256, 0.0f, aux, 0, sig);         // L3
-    layer16<8, 16, 0, true>(st, lane, h, cur, fromY, X, bias + 4 * 256, 0.0f, aux, 0, sig);         // L4
-    layer16<8, 20, 0, true>(st, lane, h, cur, fromXE, Y, bias + 5 * 256, 0.0f, aux, 0, sig);        // L5 (skip)
-    layer16<8, 16, 0, true>(st, lane, h, cur, fromY, X, bias + 6 * 256, 0.0f, aux, 0, sig);         // L6
+    layer16<16, 2, 0, true>(st, lane, g, cur, fromE, X, bias, 0.0f, hw, 0, sig);                    // L0
+    layer16<16, 8, 0, true>(st, lane, g, cur, fromX, Y, bias + 1 * 256, 0.0f, hw, 0, sig);          // L1
+    layer16<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 2 * 256, 0.0f, hw, 0, sig);          // L2
+    layer16<16, 8, 0, true>(st, lane, g, cur, fromX, Y, bias + 3 * 256, 0.0f, hw, 0, sig);          // L3
+    layer16<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 4 * 256, 0.0f, hw, 0, sig);          // L4
+    layer16<16, 10, 0, true>(st, lane, g, cur, fromXE, Y, bias + 5 * 256, 0.0f, hw, 0, sig);        // L5 (skip)
+    layer16<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 6 * 256, 0.0f, hw, 0, sig);          // L6
+    auto over_groups = [](float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
     if constexpr (VIEWDIRS) {
-        layer16<8, 16, 1, true>(st, lane, h, cur, fromX, Y, bias + 7 * 256, 0.0f, aux + AUX_HEAD, 0, sig);   // L7 + alpha
-        layer16<8, 16, 0, true>(st, lane, h, cur, fromY, X, bias + 8 * 256, NOCLAMP, aux, 0, sig);           // feature
-        layer16<4, 18, 3, false>(st, lane, h, cur, fromXD, Y, bias + 9 * 256, 0.0f, aux + AUX_HEAD + 256, 128, rgb);  // views + rgb
-        const float* hb = aux + AUX_HEAD + 256 + 384;
-        float o4[4];
+        layer16<16, 8, 1, true>(st, lane, g, cur, fromX, Y, bias + 7 * 256, 0.0f, hw, 0, sig);      // L7 + alpha head
+        layer16<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 8 * 256, NOCLAMP, hw, 0, sig);   // feature
+        layer16<8, 9, 3, false>(st, lane, g, cur, fromXD, Y, bias + 9 * 256, 0.0f, hw + 256, 128, rgb);   // views + rgb heads
+        const float* hb = hw + 256 + 384;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o4[k] = rgb[k] + __shfl_xor(rgb[k], 32, 64) + hb[1 + k];
-        o4[3] = sig[0] + __shfl_xor(sig[0], 32, 64) + hb[0];
-        if (valid[0] && h == 0) {
-            f32x4 o = {o4[0], o4[1], o4[2], o4[3]};
-            *reinterpret_cast<f32x4*>(out + p[0] * 4) = o;
+        for (int ct = 0; ct < 2; ++ct) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = over_groups(rgb[ct][k]) + hb[1 + k];
+            o[3] = over_groups(sig[ct][0]) + hb[0];
+            if (valid[ct] && g == ct) *reinterpret_cast<f32x4*>(out + p[ct] * 4) = o;
         }
     } else {
-        // output_linear: up to 8 rows, taken in two passes of fp32 head dot products inside the L7 epilogue
-        float h0[3] = {0.0f, 0.0f, 0.0f}, h1[3] = {0.0f, 0.0f, 0.0f};
-        (void)h1;
-        layer16<8, 16, 3, true>(st, lane, h, cur, fromX, Y, bias + 7 * 256, 0.0f, aux + AUX_HEAD, 256, h0);
+        // output_linear: rows 0..2 as fp32 head dot products inside the L7 epilogue, rows 3..7 from the rounded
+        // activations afterwards
+        layer16<16, 8, 3, true>(st, lane, g, cur, fromX, Y, bias + 7 * 256, 0.0f, hw, 256, sig);
         for (int ch = 0; ch < output_ch; ++ch) {
-            float s;
-            if (ch < 3) {
-                s = ch == 0 ? h0[0] : (ch == 1 ? h0[1] : h0[2]);
-            } else {  // rows 3..7 from the rounded activations
-                const float* wp = aux + AUX_HEAD + ch * 256;
-                s = 0.0f;
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+            for (int ct = 0; ct < 2; ++ct) {
+                float s;
+                if (ch < 3) {
+                    s = ch == 0 ? sig[ct][0] : (ch == 1 ? sig[ct][1] : sig[ct][2]);
+                } else {
+                    const float* wp = hw + ch * 256;
+                    s = 0.0f;
 #pragma unroll
-                    for (int sidx = 0; sidx < 2; ++sidx)
+                    for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            s = fmaf((float)Y[2 * t + sidx][j], wp[t * 32 + h * 16 + 8 * sidx + j], s);
+                        for (int j = 0; j < 8; ++j) s = fmaf((float)Y[ct][ks][j], wp[32 * ks + kslot_feature(g, j)], s);
+                }
+                s = over_groups(s) + hw[8 * 256 + ch];
+                if (valid[ct] && g == ct) out[p[ct] * output_ch + ch] = s;
             }
-            s = s + __shfl_xor(s, 32, 64) + aux[AUX_HEAD + output_ch * 256 + ch];
-            if (valid[0] && h == 0) out[p[0] * output_ch + ch] = s;
         }
     }
 }
 
-// fp32 stream -> bf16 stream: block b, lane, element j  <-  fp32 block 2b + (j>>2), lane, element j&3
-__global__ void __launch_bounds__(256) k_pack_bf16(int use_viewdirs, const float* __restrict__ packed_fwd,
+// flat parameters -> bf16 stream + fp32 aux tables
+__global__ void __launch_bounds__(256) k_pack_bf16(int use_viewdirs, int output_ch, const float* __restrict__ params,
                                                    char* __restrict__ out) {
     const int64_t nblk = bf16_stream_blocks(use_viewdirs);
     const int64_t padded = (int64_t)bf16_stream_slabs(use_viewdirs) * SLAB16 * 512;
-    const int64_t total = padded + AUX_FLOATS;
+    const int64_t total = padded + AUX16_FLOATS;
     unsigned short* s16 = reinterpret_cast<unsigned short*>(out);
     float* aux = reinterpret_cast<float*>(out + padded * 2);
-    const float* src_aux = packed_fwd + (int64_t)fwd_stream_blocks(use_viewdirs) * BLOCK_FLOATS;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < padded) {
             const int64_t b = i >> 9;
-            const int w = (int)(i & 511), lane = w >> 3, j = w & 7;
-            float v = 0.0f;
-            if (b < nblk) {
-                int64_t fb = 2 * b + (j >> 2);           // two fp32 blocks (4 registers each) make one bf16 block
-                if (b >= 544 && b < 704) {               // layer 5: per output tile, hidden k-steps then encoded ones
-                    const int lb = (int)b - 544, to = lb / 20, ks = lb % 20;
-                    // fp32 stream: encoded-input part at blocks 1088..1151 (8 per tile), hidden part at 1152..1407 (32 per tile)
-                    fb = ks < 16 ? 1152 + to * 32 + 2 * ks + (j >> 2) : 1088 + to * 8 + 2 * (ks - 16) + (j >> 2);
-                }
-                v = packed_fwd[fb * BLOCK_FLOATS + lane * 4 + (j & 3)];
-            }
-            const __bf16 r = (__bf16)v;
+            const int w = (int)(i & 511);
+            const int64_t src = b < nblk ? bf16_stream_source(use_viewdirs, output_ch, (int)b, w >> 3, w & 7) : -1;
+            const __bf16 r = (__bf16)(src < 0 ? 0.0f : params[src]);
             s16[i] = __builtin_bit_cast(unsigned short, r);
         } else {
-            aux[i - padded] = src_aux[i - padded];
+            const int64_t src = bf16_aux_source(use_viewdirs, output_ch, (int)(i - padded));
+            aux[i - padded] = src < 0 ? 0.0f : params[src];
         }
     }
 }
 
-constexpr size_t FWD16_LDS_BYTES = RING16_BYTES + AUX_FLOATS * sizeof(float) + (THREADS16 / 64) * 6 * 64 * 16;
+constexpr size_t FWD16_LDS_BYTES = RING16_BYTES + AUX16_FLOATS * sizeof(float) + (THREADS16 / 64) * 6 * 64 * 16;
 
 }  // namespace
 
@@ -324,9 +393,10 @@ extern "C" {
 
 int64_t nerf_mlp_packed_bf16_bytes(int use_viewdirs) { return bf16_packed_bytes(use_viewdirs); }
 
-int nerf_pack_weights_bf16(int use_viewdirs, const float* packed_fwd, void* packed_bf16, void* stream) {
-    NERF_REQUIRE(packed_fwd && packed_bf16, "nerf_pack_weights_bf16: null pointer");
-    hipLaunchKernelGGL(k_pack_bf16, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, packed_fwd,
+int nerf_pack_weights_bf16(int use_viewdirs, int output_ch, const float* params, void* packed_bf16, void* stream) {
+    NERF_REQUIRE(params && packed_bf16, "nerf_pack_weights_bf16: null pointer");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_pack_weights_bf16: output_ch=%d not in 1..8", output_ch);
+    hipLaunchKernelGGL(k_pack_bf16, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, params,
                        reinterpret_cast<char*>(packed_bf16));
     return launched("nerf_pack_weights_bf16");
 }

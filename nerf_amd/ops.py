@@ -321,10 +321,12 @@ def mlp_forward(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_fwd:
     return out
 
 
-def pack_weights_bf16(packed_fwd: torch.Tensor, use_viewdirs: bool) -> torch.Tensor:
-    out = torch.empty(lib.nerf_mlp_packed_bf16_bytes(int(use_viewdirs)), dtype=torch.uint8, device=packed_fwd.device)
-    with torch.cuda.device(packed_fwd.device):
-        check(lib.nerf_pack_weights_bf16(int(use_viewdirs), packed_fwd.data_ptr(), out.data_ptr(), _stream()))
+def pack_weights_bf16(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    flat = _f32c(flat, "params")
+    assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
+    out = torch.empty(lib.nerf_mlp_packed_bf16_bytes(int(use_viewdirs)), dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_pack_weights_bf16(int(use_viewdirs), output_ch, flat.data_ptr(), out.data_ptr(), _stream()))
     return out
 
 

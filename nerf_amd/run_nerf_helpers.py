@@ -125,9 +125,9 @@ class NeRF(nn.Module):
         return self._pack
 
     def _packed_bf16(self):
-        fwd = self._packed(False)[0]
+        flat = self._packed(False)[2]
         if self._pack16 is None:
-            self._pack16 = ops.pack_weights_bf16(fwd, self.use_viewdirs)
+            self._pack16 = ops.pack_weights_bf16(flat, self.use_viewdirs, self.output_ch)
         return self._pack16
 
     def _split_flat(self, flat: torch.Tensor):
