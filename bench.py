@@ -315,6 +315,35 @@ def main():
                               "mlp_share_of_step": round(s16 / dt16, 4), "dtype": "bf16 operands, f32 accumulate",
                               "note": "per-GPU, this rank only; tolerance vs fp32: raw within 2e-2 of scale, rgb within 1e-2"}
 
+    if world > 1 or os.environ.get("BENCH_FORCE_SHARDED"):
+        # one view cut into world_size ray slices, reassembled with one all_gather (strong scaling of a single frame);
+        # reported next to `value`, never instead of it
+        try:
+            from nerf_amd import parallel
+            from nerf_amd.run_nerf_helpers import get_rays
+
+            def frame(i):
+                with torch.no_grad():
+                    o, d = get_rays(H, W, K, poses[i])
+                    return parallel.render_sharded(H, W, K, chunk, (o, d), **kwargs)
+            frame(0)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                full = frame(i % n_views)
+            sync()
+            dts = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dts], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dts = float(t.item())
+            out["render_one_view_sharded"] = {"rays_per_s": round(rays_per_step * args.steps / dts, 1),
+                                              "ms_per_view": round(1e3 * dts / args.steps, 3), "ranks": world,
+                                              "gathered_bytes_per_view": rays_per_step * 20,
+                                              "rgb_checksum": float(full[0].double().sum().item())}
+        except Exception as exc:  # the headline number must survive a failure of this extra
+            out["render_one_view_sharded"] = {"error": repr(exc)}
+
     if not args.no_train:
         # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)
         out["train"] = time_train(models, kwargs, dev, world, 1024, 10, 3, seed=1234 + rank)
