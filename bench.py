@@ -4,7 +4,8 @@
 
 One step = one pass of the hot path over one batch of synthetic input: a no-grad render of one full
 800x800 lego-shaped view (640,000 rays, 64 coarse + 128 fine samples, white background, view
-directions, chunk 32768) through the public render() entry point — BASELINE.json configs[1].
+directions, chunk 32768) through the public render() entry point: the full-resolution render-only
+configuration the headline metric is quoted on.
 Inputs (poses, weights) are resident in HBM before the timed region.  With N > 1 every rank renders
 its own view of the orbit (rays are independent: no data-path collective), value = all rays / max
 time over ranks.

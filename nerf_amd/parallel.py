@@ -72,6 +72,41 @@ def render_sharded(H: int, W: int, K, chunk: int, rays, render_fn: Optional[Call
     return full[:, 0:3], full[:, 3], full[:, 4]
 
 
+def render_path_sharded(render_poses, hwf, K, chunk: int, render_kwargs, render_factor: int = 0,
+                        render_fn: Optional[Callable] = None, group=None):
+    """The pose loop of render_path (run_nerf.py:163-201) with the FRAMES dealt round-robin to the ranks: rank r
+    renders poses r, r + world, ...; one all_gather of the finished frames returns the whole sequence, in pose
+    order, on every rank as (rgbs [N,H,W,3], disps [N,H,W]) tensors."""
+    if render_fn is None:
+        from .run_nerf import render as render_fn
+    rank, world = _world(group)
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    H, W = int(H), int(W)
+    n = len(render_poses)
+    per = (n + world - 1) // world
+    mine = []
+    for i in range(rank, n, world):
+        rgb, disp, _, _ = render_fn(H, W, K, chunk=chunk, c2w=render_poses[i][:3, :4], **render_kwargs)
+        mine.append(torch.cat([rgb.reshape(H, W, 3), disp.reshape(H, W, 1)], -1))
+    dev, dtype = (mine[0].device, mine[0].dtype) if mine else (None, torch.float32)
+    if world == 1:
+        frames = torch.stack(mine, 0)
+    else:
+        if dev is None:   # more ranks than frames: this rank has nothing to render but still joins the collective
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        block = torch.zeros((per, H, W, 4), dtype=dtype, device=dev)
+        if mine:
+            block[: len(mine)] = torch.stack(mine, 0)
+        out = torch.empty((world * per, H, W, 4), dtype=dtype, device=dev)
+        dist.all_gather_into_tensor(out, block, group=group)
+        # frame i was rendered by rank i % world as its (i // world)-th
+        order = torch.tensor([(i % world) * per + i // world for i in range(n)], device=dev)
+        frames = out[order]
+    return frames[..., :3], frames[..., 3]
+
+
 def flatten_gradients(params: Sequence[torch.Tensor]) -> torch.Tensor:
     """One contiguous fp32 bucket holding every gradient (zeros where a parameter has none)."""
     chunks = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]

@@ -64,6 +64,29 @@ def test_render_sharded_reassembles_image_on_every_rank():
     assert _run(_sharded, world=3) == [True, True, True]
 
 
+def _fake_frame(H, W, K, chunk, c2w, **kw):
+    base = c2w[:3, 3].sum() + torch.arange(H * W, dtype=torch.float32).reshape(H, W)
+    return [torch.stack([base, base * 2, base * 3], -1), base * 0.5, None, {}]
+
+
+def _frames(rank, world):
+    from nerf_amd.parallel import render_path_sharded
+    ok = True
+    for n in (5, 1, 4):          # more, fewer and as many frames as a multiple of the ranks
+        poses = torch.zeros(n, 4, 4)
+        poses[:, 0, 3] = torch.arange(n, dtype=torch.float32) * 100.0
+        rgbs, disps = render_path_sharded(poses, [6, 8, 10.0], None, 16, {}, render_factor=2, render_fn=_fake_frame)
+        want = [_fake_frame(3, 4, None, 16, poses[i]) for i in range(n)]
+        ok = ok and rgbs.shape == (n, 3, 4, 3) and disps.shape == (n, 3, 4)
+        ok = ok and all(torch.equal(rgbs[i], want[i][0]) and torch.equal(disps[i], want[i][1]) for i in range(n))
+    return bool(ok)
+
+
+def test_render_path_sharded_returns_frames_in_pose_order():
+    assert _run(_frames) == [True, True]
+    assert _run(_frames, world=3) == [True, True, True]
+
+
 def _dp(rank, world):
     from nerf_amd.parallel import allreduce_gradients, broadcast_parameters
     torch.manual_seed(100 + rank)  # ranks start apart, as independently initialised processes would
