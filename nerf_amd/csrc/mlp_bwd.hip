@@ -4,8 +4,8 @@
 //  1. k_mlp_bwd_data: dL/d(pre-activation) of every layer.  Same structure as the forward: one
 //     wavefront carries 32 points, gradients live in MFMA accumulator tiles and feed the next
 //     (earlier) layer's W^T product straight from registers; the transposed weights stream through
-//     the LDS slab ring.  ReLU masks come from the saved activations; each layer's dY is written
-//     feature-major next to them.                                      Bound: MFMA (9088 per 32 points).
+//     the LDS slab ring.  ReLU masks are the bit words the forward left behind each tile (16 bytes per lane
+//     and layer instead of a 512-byte re-read of the activations); each layer's dY is written in the blocked layout.                                      Bound: MFMA (9088 per 32 points).
 //  2. k_dw_gemm: dW_l = dY_l * X_l^T, a reduction over points.  Both operands live in the blocked
 //     layout (mlp_layout.hpp): a chunk of 32 points is 512 contiguous bytes per group of four rows,
 //     copied as-is into LDS, where a lane's ds_read_b128 yields four rows of one point = the A (or B)
@@ -29,18 +29,6 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // Register tiles <-> blocked layout: `rows` = first row group of the tiles inside this workgroup's tile,
 // lane_off = half * GROUP_FLOATS + 4 * (point in tile); one 16-byte access per register quad.
-template <int NT>
-__device__ __forceinline__ void load_tiles(f32x16 (&M)[8], const float* rows, uint32_t lane_off) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rows + (8 * t + 2 * i) * GROUP_FLOATS + lane_off);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) M[t][4 * i + e] = v[e];
-        }
-}
-
 template <int NT>
 __device__ __forceinline__ void store_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off) {
 #pragma unroll
@@ -83,7 +71,11 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
     __syncthreads();
     st.fetch(0);
 
-    f32x16 A[8], B[8], M[8];
+    f32x16 A[8], B[8];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // ReLU mask of masked layer m as the forward left it: bit 16 (t % 2) + r of dword t / 2 <-> register r of tile t
+    auto mask_word = [&](int m) { return *reinterpret_cast<const u32x4*>(at + act_mask_offset(VIEWDIRS ? 1 : 0, m, wave, lane)); };
+    auto on = [](const u32x4& mw, int t, int r) { return ((mw[t >> 1] >> (16 * (t & 1) + r)) & 1u) != 0u; };
     float d_sigma = 0.0f;
     int first_layer;  // the pts layer whose output gradient the first 256x256 section produces
     if constexpr (VIEWDIRS) {
@@ -96,7 +88,7 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
             *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD2) + pw * 4) = gb;
         }
         // views layer: d(hidden) = Wrgb^T d_rgb, masked by the saved post-ReLU activations
-        load_tiles<4>(M, rows_of(at, ACT_VIEWS), lane_off);
+        const u32x4 mv = mask_word(8);
         const float* wrgb = aux + AUX_HEAD + 256;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -108,7 +100,7 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = fmaf(w2[e], g[2], fmaf(w1[e], g[1], w0[e] * g[0]));
-                    A[t][4 * i + e] = M[t][4 * i + e] > 0.0f ? v : 0.0f;
+                    A[t][4 * i + e] = on(mv, t, 4 * i + e) ? v : 0.0f;
                 }
             }
         store_tiles<4>(A, rows_of(st_, SCR_VIEWS), lane_off);
@@ -128,14 +120,14 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
             *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD) + pw * 4) = ga;
             *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD + 4) + pw * 4) = gb;
         }
-        load_tiles<8>(M, rows_of(at, ACT_H0 + 7 * 256), lane_off);
+        const u32x4 m7 = mask_word(7);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = 0.0f;
                 for (int c = 0; c < output_ch; ++c) v = fmaf(aux[AUX_HEAD + c * 256 + t * 32 + h * 16 + r], g[c], v);
-                A[t][r] = M[t][r] > 0.0f ? v : 0.0f;
+                A[t][r] = on(m7, t, r) ? v : 0.0f;
             }
         store_tiles<8>(A, rows_of(st_, SCR_H0 + 7 * 256), lane_off);
         first_layer = 6;
@@ -143,8 +135,8 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
 
 #pragma unroll 1
     for (int l = first_layer; l >= 0; --l) {
-        // saved output of pts layer l (ReLU mask), requested before the matrix work that hides its latency
-        load_tiles<8>(M, rows_of(at, ACT_H0 + 256 * l), lane_off);
+        // ReLU mask of pts layer l, requested before the matrix work that hides its latency
+        const u32x4 ml = mask_word(l);
         run_section<8, 8, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return A[ti]; });
         if (VIEWDIRS && l == 7) {
             const float* wa = aux + AUX_HEAD;
@@ -160,7 +152,7 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) A[t][r] = M[t][r] > 0.0f ? B[t][r] : 0.0f;
+            for (int r = 0; r < 16; ++r) A[t][r] = on(ml, t, r) ? B[t][r] : 0.0f;
         store_tiles<8>(A, rows_of(st_, SCR_H0 + 256 * l), lane_off);
     }
 }

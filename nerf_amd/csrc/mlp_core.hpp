@@ -100,18 +100,21 @@ __device__ __forceinline__ void run_section(Stream& st, int lane, f32x16 (&acc)[
 // One forward layer (or one of the two sections of the skip layer) on ping-pong tile arrays:
 //     out[to] = act( start + sum_ti W(to, ti) in[ti] ),   start = bias column (bias_on) or out[to]'s current value.
 // The bias is not added afterwards: a tile's accumulator registers are loaded with its bias column from LDS while
-// the previous tile is still multiplying.  ReLU runs in place on tile to-1 behind the first MFMAs of tile to, in
-// the shadow of the matrix pipe; only the last tile's ReLU is exposed.  `bias_h` = bias table + 16 * lane half.
-// `side` is called once per output tile (side.template operator()<to>()), a few blocks into the tile: work that
-// only READS the layer's inputs (storing them for the backward pass) and so can ride in the MFMA shadow as well.
+// the previous tile is still multiplying.  Everything else that has to happen to a finished tile rides in the
+// shadow of the matrix pipe, behind weight blocks of the NEXT tile: ReLU in place behind its third block; in training the
+// ReLU mask bits (bit 16 (t % 2) + r of dword t / 2 of mask_bits <-> register r of tile t positive: the
+// backward-data kernel masks with these 16 bytes per lane instead of re-reading the activations); and `side`,
+// called once per block as side.template operator()<to, block in tile>(), for work that only READS the layer's
+// inputs (storing them for the backward pass).  Only the last tile's ReLU is exposed.
+// `bias_h` = bias table + 16 * lane half.
 struct NoSide {
-    template <int TO> __device__ __forceinline__ void operator()() const {}
+    template <int TO, int BI> __device__ __forceinline__ void operator()() const {}
 };
-template <int NOUT, int NIN, bool RELU, typename InTile, typename Side = NoSide>
+template <int NOUT, int NIN, bool RELU, bool MASK, typename InTile, typename Side>
 __device__ __forceinline__ void run_layer(Stream& st, int lane, f32x16 (&out)[8], InTile in_tile, const float* bias_h,
-                                          bool bias_on, Side side = Side{}) {
-    constexpr int NB = NOUT * NIN * 4, DEPTH = 2;
-    static_assert(NIN * 4 >= 4, "a tile spans at least four blocks");
+                                          bool bias_on, Side side, uint32_t (&mask_bits)[4]) {
+    constexpr int BPT = NIN * 4, NB = NOUT * BPT, DEPTH = 2;   // blocks per tile, per layer
+    static_assert(BPT >= 8, "a tile spans at least eight blocks");
     f32x4 abuf[DEPTH + 1];
     const float* cur = nullptr;
     auto load_bias = [&]<int TO>() {
@@ -124,10 +127,15 @@ __device__ __forceinline__ void run_layer(Stream& st, int lane, f32x16 (&out)[8]
             }
         }
     };
-    auto relu = [&]<int TO>() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[TO][r] = fmaxf(out[TO][r], 0.0f);
+    auto relu = [&]<int TO, int R>() {
+        const float y = fmaxf(out[TO][R], 0.0f);
+        out[TO][R] = y;
+        if constexpr (MASK) {   // y >= 0, so "positive" = "bits != 0"
+            const uint32_t one = __float_as_uint(y) < 1u ? __float_as_uint(y) : 1u;
+            mask_bits[TO >> 1] |= one << (16 * (TO & 1) + R);
+        }
     };
+    if constexpr (MASK) mask_bits[0] = mask_bits[1] = mask_bits[2] = mask_bits[3] = 0u;
     load_bias.template operator()<0>();
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
@@ -136,17 +144,19 @@ __device__ __forceinline__ void run_layer(Stream& st, int lane, f32x16 (&out)[8]
         }
         if constexpr (I >= DEPTH) {
             constexpr int b = I - DEPTH;
-            constexpr int to = b / (NIN * 4), ti = (b >> 2) % NIN, q = b & 3;
+            constexpr int to = b / BPT, bi = b % BPT, ti = bi >> 2, q = bi & 3;
             const f32x4 a = abuf[b % (DEPTH + 1)];
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[to] = mfma(a[e], in_tile.template operator()<ti>()[4 * q + e], out[to]);
             if constexpr (ti == NIN - 1 && q == 0 && to + 1 < NOUT) load_bias.template operator()<to + 1>();
-            if constexpr (RELU && to > 0 && ti == 0 && q == 2) relu.template operator()<to - 1>();
-            if constexpr (ti == 1 && q == 0) side.template operator()<to>();
+            // (one burst behind the third block: spread thinner, one register per block, it measured 1 % slower --
+            // every visit pays the accumulator-file round trip and its wait states)
+            if constexpr (RELU && to > 0 && bi == 2) static_for<16>([&]<int R>() { relu.template operator()<to - 1, R>(); });
+            side.template operator()<to, bi>();
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (RELU) relu.template operator()<NOUT - 1>();
+    if constexpr (RELU) static_for<16>([&]<int R>() { relu.template operator()<NOUT - 1, R>(); });
 }
 
 }  // namespace nerfmlp

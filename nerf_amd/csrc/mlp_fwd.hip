@@ -27,17 +27,14 @@ namespace {
 // registers 4i..4i+3 of a tile are rows 8i + 4*half + 0..3, i.e. one row group = one 16-byte store.
 // Padding points of the last tile carry the activations of the last real point: finite values that the
 // backward multiplies by exactly-zero gradients.
-template <int T>
-__device__ __forceinline__ void save_tile(const f32x16& a, float* rows, uint32_t lane_off) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x4 v = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
-        *reinterpret_cast<f32x4*>(rows + (8 * T + 2 * i) * GROUP_FLOATS + lane_off) = v;
-    }
+template <int T, int I>   // register quad I of tile T: one row group, one 16-byte store
+__device__ __forceinline__ void save_quad(const f32x16& a, float* rows, uint32_t lane_off) {
+    const f32x4 v = {a[4 * I], a[4 * I + 1], a[4 * I + 2], a[4 * I + 3]};
+    *reinterpret_cast<f32x4*>(rows + (8 * T + 2 * I) * GROUP_FLOATS + lane_off) = v;
 }
 template <int NT>
 __device__ __forceinline__ void save_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off) {
-    static_for<NT>([&]<int T>() { save_tile<T>(A[T], rows, lane_off); });
+    static_for<NT * 4>([&]<int K>() { save_quad<K / 4, K % 4>(A[K / 4], rows, lane_off); });
 }
 
 // dot product of the register-resident activations (NT tiles) with a head row stored as [tile][half][16]
@@ -76,6 +73,7 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
     const int64_t pl = valid ? p : n_pts - 1;
     constexpr bool save = SAVE;
     // this workgroup's tile of the saved activations, and this lane's point inside it
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     float* const tile = save ? act + (int64_t)blockIdx.x * act_rows(VIEWDIRS ? 1 : 0) * TILE_PTS : nullptr;
     const int pw = wave * 32 + (lane & 31);
 
@@ -180,31 +178,52 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
     auto rows = [&](int row) { return tile + (row / 4) * GROUP_FLOATS; };
 
     // Training: a layer's output is stored for the backward pass while the NEXT layer, which only reads it,
-    // is multiplying (one tile's four 16-byte stores per output tile of that layer).
+    // is multiplying: one 16-byte store behind every other weight block of the second half of each output tile.
     float* srows = nullptr;   // first row group of the array being stored
-    auto saveP = [&]<int TO>() { if constexpr (save) save_tile<TO>(P[TO], srows, lane_off); };
-    auto saveQ = [&]<int TO>() { if constexpr (save) save_tile<TO>(Q[TO], srows, lane_off); };
+    auto saveP = [&]<int TO, int BI>() {
+        if constexpr (save && BI >= 16 && BI < 24 && (BI & 1) == 0) save_quad<TO, (BI - 16) / 2>(P[TO], srows, lane_off);
+    };
+    auto saveQ = [&]<int TO, int BI>() {
+        if constexpr (save && BI >= 16 && BI < 24 && (BI & 1) == 0) save_quad<TO, (BI - 16) / 2>(Q[TO], srows, lane_off);
+    };
 
-    run_layer<8, 2, true>(st, lane, P, inE, bias_h, true);                       // layer 0: encoded position -> P
+    // ... and every ReLU layer leaves its mask bits (16 bytes per lane) behind the tile's rows.
+    uint32_t mb[4] = {0u, 0u, 0u, 0u};
+    auto put_mask = [&](int m) {
+        if constexpr (save) {
+            const u32x4 w = {mb[0], mb[1], mb[2], mb[3]};
+            *reinterpret_cast<u32x4*>(tile + act_mask_offset(VIEWDIRS ? 1 : 0, m, wave, lane)) = w;
+        }
+    };
+
+    run_layer<8, 2, true, save>(st, lane, P, inE, bias_h, true, NoSide{}, mb);    // layer 0: encoded position -> P
+    put_mask(0);
 #pragma unroll 1
     for (int l = 1; l < 7; l += 2) {                                             // layers (1,2) (3,4) (5,6): P -> Q -> P
-        if (l == 5) run_layer<8, 2, false>(st, lane, Q, inE, bias_h + 5 * 256, true);   // skip: encoded inputs first
+        if (l == 5) run_layer<8, 2, false, false>(st, lane, Q, inE, bias_h + 5 * 256, true, NoSide{}, mb);   // skip: encoded inputs first
         if constexpr (save) srows = rows(ACT_H0 + 256 * (l - 1));
-        run_layer<8, 8, true>(st, lane, Q, inP, bias_h + l * 256, l != 5, saveP);
+        run_layer<8, 8, true, save>(st, lane, Q, inP, bias_h + l * 256, l != 5, saveP, mb);
+        put_mask(l);
         if constexpr (save) srows = rows(ACT_H0 + 256 * l);
-        run_layer<8, 8, true>(st, lane, P, inQ, bias_h + (l + 1) * 256, true, saveQ);
+        run_layer<8, 8, true, save>(st, lane, P, inQ, bias_h + (l + 1) * 256, true, saveQ, mb);
+        put_mask(l + 1);
     }
     if constexpr (save) srows = rows(ACT_H0 + 256 * 6);
-    run_layer<8, 8, true>(st, lane, Q, inP, bias_h + 7 * 256, true, saveP);      // layer 7: P -> Q
+    run_layer<8, 8, true, save>(st, lane, Q, inP, bias_h + 7 * 256, true, saveP, mb);  // layer 7: P -> Q
+    put_mask(7);
 
     if (VIEWDIRS) {
         const float sigma = head_dot<8>(Q, aux + AUX_HEAD, h) + aux[AUX_HEAD + 256 + 384];
         if constexpr (save) srows = rows(ACT_H0 + 256 * 7);
-        run_layer<8, 8, false>(st, lane, P, inQ, bias_h + 8 * 256, true, saveQ); // feature_linear (no activation): Q -> P
+        run_layer<8, 8, false, false>(st, lane, P, inQ, bias_h + 8 * 256, true, saveQ, mb); // feature_linear (no activation): Q -> P
         if constexpr (save) srows = rows(ACT_FEAT);
-        run_layer<4, 9, true>(st, lane, Q, [&]<int ti>() -> const f32x16& { if constexpr (ti < 8) return P[ti]; else return D; },
+        run_layer<4, 9, true, save>(st, lane, Q, [&]<int ti>() -> const f32x16& { if constexpr (ti < 8) return P[ti]; else return D; },
                               bias_h + 9 * 256, true,                            // views layer: P ++ D -> Q[0..3]
-                              [&]<int TO>() { saveP.template operator()<2 * TO>(); saveP.template operator()<2 * TO + 1>(); });
+                              [&]<int TO, int BI>() {   // four output tiles read eight input tiles: eight stores per tile
+                                  if constexpr (save && BI >= 16 && BI < 32 && (BI & 1) == 0)
+                                      save_quad<2 * TO + (BI - 16) / 8, ((BI - 16) / 2) % 4>(P[2 * TO + (BI - 16) / 8], srows, lane_off);
+                              }, mb);
+        put_mask(8);
         if constexpr (save) save_tiles<4>(Q, rows(ACT_VIEWS), lane_off);
         const float* wrgb = aux + AUX_HEAD + 256;
         const float* hb = aux + AUX_HEAD + 256 + 384;

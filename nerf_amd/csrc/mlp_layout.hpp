@@ -228,10 +228,19 @@ NL_HD inline int64_t bwd_source(int use_viewdirs, int output_ch, int64_t idx) {
 //   rows   0.. 63  encoded positions (row 63 zero)        rows 64.. 95  encoded directions (27 used)
 //   rows  96+256*l .. +255  output of pts layer l after ReLU (l = 0..7)
 //   rows 2144..2399 feature_linear output                  rows 2400..2527 views layer output after ReLU
+// Behind the rows of a tile: the ReLU masks, one bit per activation, as the backward-data kernel wants them:
+// 9 masked layers (pts 0..7, views) x [wave 4][lane 64] x 128 bits; bit 16 (t%2) + r of dword t/2 = "register r of
+// tile t of this lane was positive".  Two row groups (4 KiB) per layer, 72 rows in all.
 constexpr int ACT_ENC_PTS = 0, ACT_ENC_DIRS = 64, ACT_H0 = 96, ACT_FEAT = 96 + 8 * 256, ACT_VIEWS = ACT_FEAT + 256;
 constexpr int ACT_ROWS = ACT_VIEWS + 128;
+constexpr int ACT_MASK_ROWS = 9 * 8;
 constexpr int GROUP_FLOATS = TILE_PTS * 4;   // one group: 4 rows x 128 points
-NL_HD constexpr int act_rows(int use_viewdirs) { return use_viewdirs ? ACT_ROWS : ACT_FEAT; }
+NL_HD constexpr int act_data_rows(int use_viewdirs) { return use_viewdirs ? ACT_ROWS : ACT_FEAT; }
+NL_HD constexpr int act_rows(int use_viewdirs) { return act_data_rows(use_viewdirs) + ACT_MASK_ROWS; }
+// float offset, inside a tile, of this lane's 16-byte mask word of masked layer m (0..7: pts layers, 8: views layer)
+NL_HD constexpr int act_mask_offset(int use_viewdirs, int m, int wave, int lane) {
+    return (act_data_rows(use_viewdirs) / 4 + 2 * m) * GROUP_FLOATS + (wave * 64 + lane) * 4;
+}
 NL_HD inline int64_t padded_points(int64_t n_pts) { return (n_pts + TILE_PTS - 1) / TILE_PTS * TILE_PTS; }
 NL_HD inline int64_t act_floats(int use_viewdirs, int64_t n_pts) {
     return (int64_t)act_rows(use_viewdirs) * padded_points(n_pts);
@@ -251,7 +260,8 @@ NL_HD inline int64_t blocked_index(int rows_per_tile, int row, int64_t p) {
 constexpr int SCR_H0 = 0, SCR_FEAT = 8 * 256, SCR_VIEWS = SCR_FEAT + 256;
 NL_HD constexpr int scr_head(int use_viewdirs) { return use_viewdirs ? SCR_VIEWS + 128 : 8 * 256; }
 NL_HD constexpr int scr_rows(int use_viewdirs) { return act_rows(use_viewdirs); }
-static_assert(SCR_VIEWS + 128 + 64 <= ACT_ROWS && 8 * 256 + 64 <= ACT_FEAT, "head rows fit below the activations' row count");
+static_assert(SCR_VIEWS + 128 + 64 <= ACT_ROWS + ACT_MASK_ROWS && 8 * 256 + 64 <= ACT_FEAT + ACT_MASK_ROWS,
+              "head rows fit below the activations' row count");
 constexpr int KSPLIT = 32;               // upper bound of point-range slices per weight tile
 NL_HD inline int64_t slab_floats(int use_viewdirs, int output_ch) {
     return (param_offsets(use_viewdirs, output_ch).total + 63) / 64 * 64;
