@@ -4,8 +4,8 @@
 // raw[ray][s0+i] as one 16-byte vector, so a wave reads 1 KiB of contiguous HBM per tile.  The
 // exclusive transmittance product is a 64-lane Hillis-Steele scan carried in fp64 (the PyTorch CPU
 // cumprod accumulates in fp64 and rounds each element to fp32; an fp64 scan reproduces those
-// roundings up to double rounding), with a scalar carry between tiles.  Ray sums are fp64 wave
-// reductions.  HBM-bound: 24*S + 36 bytes per ray forward, 36*S + 24 backward (+4*S with noise).
+// roundings up to double rounding), with a scalar carry between tiles.  Ray sums are fp32, like the
+// reference's: per-lane partial sums over the tiles, then a balanced DPP tree over the lanes.  HBM-bound: 24*S + 36 bytes per ray forward, 36*S + 24 backward (+4*S with noise).
 #include "common.hpp"
 #include "wave_ops.hpp"
 #pragma clang fp contract(off)
@@ -16,8 +16,6 @@ namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_TILES = 64;  // backward keeps one carry per 64-sample tile: S <= 4096
-
-__device__ __forceinline__ double wave_sum(double v) { return wave_reduce_f64<OpAdd>(v); }
 
 struct Sample {
     float4 raw;
@@ -57,7 +55,7 @@ k_composite_fwd(int64_t n, int S, const float* __restrict__ raw, const float* __
         const float dnorm = ray_norm(rays + ray * ld);
         const int64_t base = ray * S;
         double carry = 1.0;  // product of keep over all earlier tiles
-        double sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;
+        float sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;   // this lane's share of the ray sums (fp32, like the reference's)
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int s = s0 + lane;
             const bool live = s < S;
@@ -75,17 +73,17 @@ k_composite_fwd(int64_t n, int S, const float* __restrict__ raw, const float* __
             if (live) {
                 const float w = q.alpha * T;
                 weights[base + s] = w;
-                sr += (double)(w * sigmoidf(q.raw.x));
-                sg += (double)(w * sigmoidf(q.raw.y));
-                sb += (double)(w * sigmoidf(q.raw.z));
-                sd += (double)(w * q.z);
-                sa += (double)w;
+                sr = sr + w * sigmoidf(q.raw.x);
+                sg = sg + w * sigmoidf(q.raw.y);
+                sb = sb + w * sigmoidf(q.raw.z);
+                sd = sd + w * q.z;
+                sa = sa + w;
             }
         }
-        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+        sr = wave_sum_f32(sr); sg = wave_sum_f32(sg); sb = wave_sum_f32(sb); sd = wave_sum_f32(sd); sa = wave_sum_f32(sa);
         if (lane == 0) {
-            const float a = (float)sa, d = (float)sd;
-            float r = (float)sr, g = (float)sg, b = (float)sb;
+            const float a = sa, d = sd;
+            float r = sr, g = sg, b = sb;
             if (white) {
                 const float bg = 1.0f - a;
                 r = r + bg; g = g + bg; b = b + bg;
@@ -123,13 +121,13 @@ k_composite_bwd(int64_t n, int S, const float* __restrict__ raw, const float* __
         if (white) ga = ga - ((gr + gg) + gb);
         if (g_disp) {
             // disp = 1 / max(1e-10, depth/acc): needs the forward sums again
-            double sd = 0, sa = 0;
+            float sd = 0, sa = 0;
             for (int s = lane; s < S; s += 64) {
                 const float w = weights[base + s];
-                sd += (double)(w * z[base + s]);
-                sa += (double)w;
+                sd = sd + w * z[base + s];
+                sa = sa + w;
             }
-            const float d = (float)wave_sum(sd), a = (float)wave_sum(sa);
+            const float d = wave_sum_f32(sd), a = wave_sum_f32(sa);
             const float q = d / a;
             if (q > 1e-10f) {
                 const float gq = -g_disp[ray] / (q * q);

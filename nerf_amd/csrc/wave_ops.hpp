@@ -7,6 +7,7 @@
 // the operation's identity here.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace nerfhip {
 
@@ -44,6 +45,23 @@ __device__ __forceinline__ double wave_scan_f64(double v) {
     s = Op::apply(s, dpp_f64<0x142, 0xa, 0xf>(id, s));             // row_bcast:15 into rows 1 and 3
     s = Op::apply(s, dpp_f64<0x143, 0xc, 0xf>(id, s));             // row_bcast:31 into rows 2 and 3
     return s;
+}
+
+// fp32 sum over all 64 lanes, returned in every lane: a balanced tree (row_shr 1/2/4/8 inside rows of 16, then the
+// row totals), rounding error <= 6 half-ulps of the sum of magnitudes.  The shifted-in value of a lane without a
+// source is 0 (bound_ctrl), so after the row steps lane 15 of each row holds the row total.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    auto shr = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += shr(v, std::integral_constant<int, 0x111>{});
+    v += shr(v, std::integral_constant<int, 0x112>{});
+    v += shr(v, std::integral_constant<int, 0x114>{});
+    v += shr(v, std::integral_constant<int, 0x118>{});
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)) +
+           (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47)) +
+            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)));
 }
 
 // op over all 64 lanes, returned in every lane (wave-uniform)
