@@ -114,14 +114,16 @@ def flatten_gradients(params: Sequence[torch.Tensor]) -> torch.Tensor:
 
 
 def unflatten_into_gradients(bucket: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
-    off = 0
+    """Copy the bucket back into the .grad tensors: one multi-tensor copy, not one launch per parameter."""
+    off, dst, src = 0, [], []
     for p in params:
         g = bucket[off: off + p.numel()].view_as(p)
         if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+            p.grad = torch.empty_like(p)
+        dst.append(p.grad)
+        src.append(g)
         off += p.numel()
+    torch._foreach_copy_(dst, src)
 
 
 def allreduce_gradients(params: Iterable[torch.Tensor], group=None) -> None:
