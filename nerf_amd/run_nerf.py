@@ -32,7 +32,7 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     """run_nerf.py:40-66.  With the module's own NeRF and embedders the encoding, the concatenation and
     every layer run as ONE fused kernel over all points; netchunk (a memory knob upstream) then has
     nothing to bound.  Any other `fn` gets the encoded features in netchunk slices, as upstream."""
-    fused = (isinstance(fn, NeRF) and getattr(embed_fn, 'n_freq', None) == 10
+    fused = (isinstance(fn, NeRF) and fn.fused_arch() and getattr(embed_fn, 'n_freq', None) == 10
              and (viewdirs is None or getattr(embeddirs_fn, 'n_freq', None) == 4)
              and fn.use_viewdirs == (viewdirs is not None))
     if fused:

@@ -66,7 +66,9 @@ class NeRF(nn.Module):
     """Same constructor, attributes and state_dict as upstream; forward runs the fused MFMA kernel.
 
     The kernel exists for the architecture every upstream config uses: D=8, W=256, skips=[4],
-    input_ch=63 (L=10), input_ch_views=27 (L=4) or no view branch.  Other shapes raise."""
+    input_ch=63 (L=10), input_ch_views=27 (L=4) or no view branch.  Any other shape (other --netdepth /
+    --netwidth / --multires) runs layer by layer through the GPU BLAS via torch.nn.functional -- same
+    results, autograd included, none of the fusion."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super(NeRF, self).__init__()
@@ -97,11 +99,14 @@ class NeRF(nn.Module):
         self.mlp_dtype = 'f32'
 
     # -- kernel plumbing ---------------------------------------------------------------------------
+    def fused_arch(self) -> bool:
+        """Whether the hand-written kernels cover this module's shape."""
+        return (self.D == 8 and self.W == 256 and list(self.skips) == [4] and self.input_ch == 63
+                and ((self.use_viewdirs and self.input_ch_views == 27) or
+                     (not self.use_viewdirs and self.input_ch_views == 0 and 1 <= self.output_ch <= 8)))
+
     def _check_arch(self):
-        ok = (self.D == 8 and self.W == 256 and list(self.skips) == [4] and self.input_ch == 63
-              and ((self.use_viewdirs and self.input_ch_views == 27) or
-                   (not self.use_viewdirs and self.input_ch_views == 0 and 1 <= self.output_ch <= 8)))
-        if not ok:
+        if not self.fused_arch():
             raise NotImplementedError(
                 f"NeRF(D={self.D}, W={self.W}, skips={self.skips}, input_ch={self.input_ch}, "
                 f"input_ch_views={self.input_ch_views}, use_viewdirs={self.use_viewdirs}): the fused HIP kernel "
@@ -146,8 +151,28 @@ class NeRF(nn.Module):
         The render path does not come through here (run_network fuses the encoding); gradients flow to the
         parameters only."""
         x = ops.to_dev(x)
+        if not self.fused_arch():
+            return self._forward_layers(x)
         out = ops.fused_mlp(x.reshape(-1, x.shape[-1]), None, self, 0)
         return out.reshape(list(x.shape[:-1]) + [out.shape[-1]])
+
+    def _forward_layers(self, x):
+        """The module's definition, one library GEMM per layer (run_nerf_helpers.py:109-133), for shapes the fused
+        kernels do not cover."""
+        F = torch.nn.functional
+        pts, views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        h = pts
+        for i, layer in enumerate(self.pts_linears):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([pts, h], -1)
+        if not self.use_viewdirs:
+            return self.output_linear(h)
+        alpha = self.alpha_linear(h)
+        h = torch.cat([self.feature_linear(h), views], -1)
+        for layer in self.views_linears:
+            h = F.relu(layer(h))
+        return torch.cat([self.rgb_linear(h), alpha], -1)
 
     def load_weights_from_keras(self, weights):
         """run_nerf_helpers.py:136-163."""

@@ -649,6 +649,42 @@ def test_nerf_forward_on_encoded_inputs_and_generic_run_network(device):
         _grad_close(p.grad, params[k].grad, "encoded-entry grad " + k)
 
 
+def test_other_network_shapes_run_layer_by_layer(device):
+    """--netdepth / --netwidth / --multires other than the shipped configs: encoding kernel + library GEMMs, same
+    numbers as the oracle, gradients included, through the same public entry points."""
+    from nerf_amd.run_nerf import render, run_network
+    from nerf_amd.run_nerf_helpers import NeRF, get_embedder
+    rng = np.random.Generator(np.random.PCG64(14))
+    e, ch = get_embedder(6, 0)
+    ed, chd = get_embedder(2, 0)
+    sd = O.random_state_dict(70, depth=4, width=128, in_pts=ch, in_dirs=chd, skips=(2,))
+    m = NeRF(D=4, W=128, input_ch=ch, input_ch_views=chd, output_ch=5, skips=[2], use_viewdirs=True)
+    m.load_state_dict(sd)
+    m = m.to(device)
+    assert not m.fused_arch()
+    qf = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=e, embeddirs_fn=ed, netchunk=1 << 16)
+    pts = T(rng.uniform(-2, 2, size=(40, 16, 3)).astype(np.float32))
+    vd = T(rng.normal(size=(40, 3)).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    raw = qf(pts.to(device), vd.to(device), m)
+    want_p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = O.query_field(pts, vd, want_p, n_freq_pts=6, n_freq_dirs=2, skips=(2,))
+    close(raw, want, 1e-4, 1e-5, "raw of a 4x128 network")
+    raw.square().sum().backward()
+    want.square().sum().backward()
+    for k, p in m.named_parameters():
+        _grad_close(p.grad, want_p[k].grad, "grad " + k, rtol=1e-3, atol_frac=1e-4)
+    rays = torch.stack([T(rng.normal(size=(30, 3)).astype(np.float32)) * 0.1 + torch.tensor([0.0, 0.0, 4.0]),
+                        T(rng.normal(size=(30, 3)).astype(np.float32)) * 0.1 - torch.tensor([0.0, 0.0, 1.0])], 0)
+    with torch.no_grad():
+        rgb, disp, acc, _ = render(8, 8, np.eye(3), chunk=1 << 15, rays=rays.to(device), network_fn=m, network_query_fn=qf,
+                                   N_samples=16, N_importance=8, network_fine=m, perturb=0.0, white_bkgd=True,
+                                   use_viewdirs=True, ndc=False, near=2.0, far=6.0)
+        got = O.render_chunks(O.pack_rays(rays[0], rays[1], 2.0, 6.0, use_viewdirs=True), 1 << 15, sd_coarse=sd, sd_fine=sd,
+                              n_coarse=16, n_fine=8, white_bkgd=True, n_freq_pts=6, n_freq_dirs=2, skips=(2,))
+    close(rgb, got["rgb_map"], 2e-4, 2e-5, "render with a 4x128 network")
+
+
 def test_create_nerf_checkpoint_roundtrip_and_render_path(device, tmp_path):
     from nerf_amd.run_nerf import config_parser, create_nerf, render_path, save_checkpoint
     (tmp_path / "exp").mkdir()
