@@ -29,8 +29,13 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int THREADS16 = 512;                // eight waves, two per SIMD
-constexpr int WG_PTS = (THREADS16 / 64) * 32; // points per workgroup
+#ifndef BF16_NCT
+#define BF16_NCT 2
+#endif
+constexpr int NCT = BF16_NCT;                 // 16-point column tiles per wave
+constexpr int THREADS16 = 1024 / NCT;         // NCT = 2: eight waves, two per SIMD; NCT = 4: four waves, one per SIMD
+constexpr int WAVE_PTS = 16 * NCT;
+constexpr int WG_PTS = (THREADS16 / 64) * WAVE_PTS;   // points per workgroup (256)
 constexpr int SLAB16 = 32;                    // 1 KiB blocks per slab
 constexpr int SLAB16_BYTES = SLAB16 * 1024;
 constexpr int RING16_BYTES = 2 * SLAB16_BYTES;
@@ -171,21 +176,21 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // row tile t+1.  Layers with at least seven k-steps start each accumulator as the tile's bias column; the two-step
 // first layer adds the bias in the epilogue.  Blocks are read DEPTH ahead, also across tiles and slab barriers.
 template <int NOUT, int NKS, int NHEAD, bool STORE, typename InFrag>
-__device__ __forceinline__ void layer16(Stream16& st, int lane, int g, const char*& cur, InFrag in_frag, bf16x8 (&Y)[2][8],
+__device__ __forceinline__ void layer16(Stream16& st, int lane, int g, const char*& cur, InFrag in_frag, bf16x8 (&Y)[NCT][8],
                                         const float* bias_lds, float lo, const float* head_lds, int head_stride,
-                                        float (&head)[2][3]) {
-    constexpr int NB = NOUT * NKS, DEPTH = 3;
+                                        float (&head)[NCT][3]) {
+    constexpr int NB = NOUT * NKS, DEPTH = 3, NPIECE = 2 * NCT;
     constexpr bool BIAS_INIT = NKS >= 7;
-    constexpr int PPS = NKS >= 4 ? 1 : 4 / NKS;   // epilogue pieces per k-step
+    constexpr int PPS = (NPIECE + (NKS < 8 ? NKS : 8) - 1) / (NKS < 8 ? NKS : 8);   // epilogue pieces per k-step
     bf16x8 abuf[DEPTH + 1];
-    f32x4 acc[2][2];                              // [alternating set][column tile]
+    f32x4 acc[2][NCT];                            // [alternating set][column tile]
     const float* bp = bias_lds + 4 * g;
     const float* hp = head_lds + 4 * g;
 
     auto load_bias = [&]<int TO>() {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + 16 * TO);
-        acc[TO & 1][0] = bb;
-        acc[TO & 1][1] = bb;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[TO & 1][ct] = bb;
     };
     auto piece = [&]<int TP, int K>() {           // K = 2 * column tile + register pair
         constexpr int ct = K >> 1, pr = K & 1;
@@ -221,29 +226,29 @@ __device__ __forceinline__ void layer16(Stream16& st, int lane, int g, const cha
             constexpr int b = I - DEPTH;
             constexpr int to = b / NKS, ks = b % NKS;
             const bf16x8 a = abuf[b % (DEPTH + 1)];
-            if constexpr (!BIAS_INIT && ks == 0) {
-                const f32x4 zero = {0, 0, 0, 0};
-                acc[to & 1][0] = mfma16(a, in_frag.template operator()<0, ks>(), zero);
-                acc[to & 1][1] = mfma16(a, in_frag.template operator()<1, ks>(), zero);
-            } else {
-                acc[to & 1][0] = mfma16(a, in_frag.template operator()<0, ks>(), acc[to & 1][0]);
-                acc[to & 1][1] = mfma16(a, in_frag.template operator()<1, ks>(), acc[to & 1][1]);
-            }
+            static_for<NCT>([&]<int CT>() {
+                if constexpr (!BIAS_INIT && ks == 0) {
+                    const f32x4 zero = {0, 0, 0, 0};
+                    acc[to & 1][CT] = mfma16(a, in_frag.template operator()<CT, ks>(), zero);
+                } else {
+                    acc[to & 1][CT] = mfma16(a, in_frag.template operator()<CT, ks>(), acc[to & 1][CT]);
+                }
+            });
             if constexpr (to > 0) {   // the previous row tile's epilogue, piece by piece, behind this tile's MFMAs
                 static_for<PPS>([&]<int Q>() {
                     constexpr int K = ks * PPS + Q;
-                    if constexpr (K < 4) piece.template operator()<to - 1, K>();
+                    if constexpr (K < NPIECE) piece.template operator()<to - 1, K>();
                 });
             }
             if constexpr (BIAS_INIT && to + 1 < NOUT && ks == NKS - 3) load_bias.template operator()<to + 1>();
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    static_for<4>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
+    static_for<NPIECE>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
 }
 
 template <bool VIEWDIRS>
-__global__ void __launch_bounds__(THREADS16, 2)
+__global__ void __launch_bounds__(THREADS16, NCT == 2 ? 2 : 1)
 k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
                int output_ch, const char* __restrict__ packed, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
@@ -258,13 +263,13 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
     }
 
     // ---- encodings: this lane's group evaluates its share of the sin/cos pairs for its two points
-    bf16x8* ed = reinterpret_cast<bf16x8*>(smem16 + RING16_BYTES + AUX16_FLOATS * 4) + wave * (6 * 64) + lane;
-    int64_t p[2];
-    bool valid[2];
+    bf16x8* ed = reinterpret_cast<bf16x8*>(smem16 + RING16_BYTES + AUX16_FLOATS * 4) + wave * (3 * NCT * 64) + lane;
+    int64_t p[NCT];
+    bool valid[NCT];
     const int c0 = enc16_first_pair(g);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        p[ct] = (int64_t)blockIdx.x * WG_PTS + wave * 32 + ct * 16 + (lane & 15);
+    for (int ct = 0; ct < NCT; ++ct) {
+        p[ct] = (int64_t)blockIdx.x * WG_PTS + wave * WAVE_PTS + ct * 16 + (lane & 15);
         valid[ct] = p[ct] < n_pts;
         const int64_t pl = valid[ct] ? p[ct] : n_pts - 1;
         const float x0 = pts[pl * 3 + 0], x1 = pts[pl * 3 + 1], x2 = pts[pl * 3 + 2];
@@ -291,7 +296,7 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
             }
             dd[6] = g == 0 ? v0 : (g == 1 ? v2 : 0.0f);
             dd[7] = g == 0 ? v1 : 0.0f;
-            ed[(4 + ct) * 64] = pack8(dd);
+            ed[(2 * NCT + ct) * 64] = pack8(dd);
         }
     }
 
@@ -305,8 +310,12 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
     st.fetch(0);
     const char* cur = nullptr;
 
-    bf16x8 X[2][8], Y[2][8];
-    float sig[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, rgb[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    bf16x8 X[NCT][8], Y[NCT][8];
+    float sig[NCT][3], rgb[NCT][3];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sig[ct][k] = rgb[ct][k] = 0.0f;
     const float NOCLAMP = -__builtin_inff();
     const float* bias = aux + AUX16_BIAS;
     const float* hw = aux + AUX16_HEAD;
@@ -315,7 +324,7 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
     auto fromX = [&]<int ct, int ks>() -> bf16x8 { return X[ct][ks]; };
     auto fromY = [&]<int ct, int ks>() -> bf16x8 { return Y[ct][ks]; };
     auto fromXE = [&]<int ct, int ks>() -> bf16x8 { if constexpr (ks < 8) return X[ct][ks]; else return ed[(2 * ct + ks - 8) * 64]; };
-    auto fromXD = [&]<int ct, int ks>() -> bf16x8 { if constexpr (ks < 8) return X[ct][ks]; else return ed[(4 + ct) * 64]; };
+    auto fromXD = [&]<int ct, int ks>() -> bf16x8 { if constexpr (ks < 8) return X[ct][ks]; else return ed[(2 * NCT + ct) * 64]; };
 
     layer16<16, 2, 0, true>(st, lane, g, cur, fromE, X, bias, 0.0f, hw, 0, sig);                    // L0
     layer16<16, 8, 0, true>(st, lane, g, cur, fromX, Y, bias + 1 * 256, 0.0f, hw, 0, sig);          // L1
@@ -331,12 +340,12 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
         layer16<8, 9, 3, false>(st, lane, g, cur, fromXD, Y, bias + 9 * 256, 0.0f, hw + 256, 128, rgb);   // views + rgb heads
         const float* hb = hw + 256 + 384;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct) {
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 3; ++k) o[k] = over_groups(rgb[ct][k]) + hb[1 + k];
             o[3] = over_groups(sig[ct][0]) + hb[0];
-            if (valid[ct] && g == ct) *reinterpret_cast<f32x4*>(out + p[ct] * 4) = o;
+            if (valid[ct] && g == (ct & 3)) *reinterpret_cast<f32x4*>(out + p[ct] * 4) = o;
         }
     } else {
         // output_linear: rows 0..2 as fp32 head dot products inside the L7 epilogue, rows 3..7 from the rounded
@@ -344,7 +353,7 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
         layer16<16, 8, 3, true>(st, lane, g, cur, fromX, Y, bias + 7 * 256, 0.0f, hw, 256, sig);
         for (int ch = 0; ch < output_ch; ++ch) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 float s;
                 if (ch < 3) {
                     s = ch == 0 ? sig[ct][0] : (ch == 1 ? sig[ct][1] : sig[ct][2]);
@@ -357,7 +366,7 @@ k_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, co
                         for (int j = 0; j < 8; ++j) s = fmaf((float)Y[ct][ks][j], wp[32 * ks + kslot_feature(g, j)], s);
                 }
                 s = over_groups(s) + hw[8 * 256 + ch];
-                if (valid[ct] && g == ct) out[p[ct] * output_ch + ch] = s;
+                if (valid[ct] && g == (ct & 3)) out[p[ct] * output_ch + ch] = s;
             }
         }
     }
@@ -385,7 +394,7 @@ __global__ void __launch_bounds__(256) k_pack_bf16(int use_viewdirs, int output_
     }
 }
 
-constexpr size_t FWD16_LDS_BYTES = RING16_BYTES + AUX16_FLOATS * sizeof(float) + (THREADS16 / 64) * 6 * 64 * 16;
+constexpr size_t FWD16_LDS_BYTES = RING16_BYTES + AUX16_FLOATS * sizeof(float) + (THREADS16 / 64) * 3 * NCT * 64 * 16;
 
 }  // namespace
 
