@@ -29,11 +29,10 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef BF16_NCT
-#define BF16_NCT 2
-#endif
-constexpr int NCT = BF16_NCT;                 // 16-point column tiles per wave
-constexpr int THREADS16 = 1024 / NCT;         // NCT = 2: eight waves, two per SIMD; NCT = 4: four waves, one per SIMD
+// 16-point column tiles per wave.  Two (eight waves per workgroup, two per SIMD) is the measured optimum: four tiles
+// at one wave per SIMD halve the LDS reads per FLOP but ran 14 % slower (no partner wave to cover barriers).
+constexpr int NCT = 2;
+constexpr int THREADS16 = 1024 / NCT;
 constexpr int WAVE_PTS = 16 * NCT;
 constexpr int WG_PTS = (THREADS16 / 64) * WAVE_PTS;   // points per workgroup (256)
 constexpr int SLAB16 = 32;                    // 1 KiB blocks per slab
