@@ -351,7 +351,7 @@ def main():
         out["train_8192"] = time_train(models, kwargs, dev, world, 8192, 4, 2, seed=4321 + rank)
 
     if rank == 0:
-        if args.cpu_rays > 0:
+        if args.cpu_rays > 0 and world == 1:   # the CPU leg is a single-GPU-run extra: ranks of a multi-GPU run do not wait for it
             cpu_rps, cpu_out, pick = cpu_baseline(sds, poses[-1].cpu(), H, W, K, args.cpu_rays)
             got = last[0].reshape(-1, 3)[pick.to(dev)].cpu()
             err = float((got - cpu_out["rgb_map"]).abs().max())

@@ -261,7 +261,11 @@ class _Composite(torch.autograd.Function):
 
 def composite(raw, z, rays_d, noise=None, white_bkgd=False):
     """-> rgb_map, disp_map, acc_map, weights, depth_map; differentiable w.r.t. raw only.
-    rays_d: [n,3], any row stride (e.g. a column slice of the packed ray records)."""
+    rays_d: [n,3], any row stride (e.g. a column slice of the packed ray records).
+    raw may carry more than 4 channels (output_ch = 5 without view directions): like run_nerf.py:323,333 only
+    channels 0..3 are read, and the others receive a zero gradient."""
+    if raw.shape[-1] > 4:
+        raw = raw[..., :4]
     return _Composite.apply(raw, z, rays_d, noise, white_bkgd)
 
 

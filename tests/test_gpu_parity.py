@@ -34,10 +34,18 @@ def exact(got, want, what):
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} differ, max|d|={np.nanmax(np.abs(got - want))}"
 
 
-def _peaky(sd, gain):
+def _peaky(sd, gain, shift=0.5):
     sd = {k: v.clone() for k, v in sd.items()}
     sd["alpha_linear.weight"] *= gain
-    sd["alpha_linear.bias"] = sd["alpha_linear.bias"] * gain + 0.5
+    sd["alpha_linear.bias"] = sd["alpha_linear.bias"] * gain + shift
+    return sd
+
+
+def _peaky_out(sd, gain, shift=0.5):
+    """_peaky for the network without view branch: density is row 3 of output_linear."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["output_linear.weight"][3] *= gain
+    sd["output_linear.bias"][3] = sd["output_linear.bias"][3] * gain + shift
     return sd
 
 
@@ -683,6 +691,83 @@ def test_other_network_shapes_run_layer_by_layer(device):
         got = O.render_chunks(O.pack_rays(rays[0], rays[1], 2.0, 6.0, use_viewdirs=True), 1 << 15, sd_coarse=sd, sd_fine=sd,
                               n_coarse=16, n_fine=8, white_bkgd=True, n_freq_pts=6, n_freq_dirs=2, skips=(2,))
     close(rgb, got["rgb_map"], 2e-4, 2e-5, "render with a 4x128 network")
+
+
+def test_render_option_paths(device):
+    """Branches of render()/render_rays() the shipped configs do not take: c2w_staticcam (view directions of one
+    camera, rays of another: run_nerf.py:120-125), network_fine=None with N_importance > 0 (the coarse network
+    answers both passes: run_nerf.py:472), rays without view directions (8 columns), and i_embed=-1 (identity
+    encoding: run_nerf_helpers.py:51-52)."""
+    from nerf_amd.run_nerf import render, run_network
+    from nerf_amd.run_nerf_helpers import NeRF, get_embedder
+    sd_c, sd_f = _peaky(O.random_state_dict(31), 6.0, 1.0), _peaky(O.random_state_dict(32), 6.0, 1.0)  # soft density: no spikes between samples
+    mc, mf = _model(sd_c, device), _model(sd_f, device)
+    qf = _query_fn()
+    H = W = 12
+    K = np.array([[16.0, 0, 6.0], [0, 16.0, 6.0], [0, 0, 1]])
+    cam, fixed = O.orbit_pose(40.0, -30.0, 4.0)[:3, :4], O.orbit_pose(95.0, -20.0, 4.0)[:3, :4]
+    kw = dict(network_fn=mc, network_query_fn=qf, N_samples=32, N_importance=24, perturb=0.0, white_bkgd=True,
+              ndc=False, near=2.0, far=6.0)
+    okw = dict(n_coarse=32, n_fine=24, white_bkgd=True)
+
+    with torch.no_grad():
+        rgb, disp, acc, ex = render(H, W, K, c2w=cam.to(device), c2w_staticcam=fixed.to(device), use_viewdirs=True,
+                                    network_fine=mf, **kw)
+        o_f, d_f = O.pixel_rays(H, W, K, fixed)
+        _, d_c = O.pixel_rays(H, W, K, cam)
+        want = O.render_chunks(O.pack_rays(o_f, d_f, 2.0, 6.0, use_viewdirs=True, viewdirs_from=d_c), 1 << 15,
+                               sd_coarse=sd_c, sd_fine=sd_f, **okw)
+    assert rgb.shape == (H, W, 3)
+    close(rgb.reshape(-1, 3), want["rgb_map"], 2e-4, 2e-5, "staticcam rgb")
+    close(ex["rgb0"].reshape(-1, 3), want["rgb0"], 2e-4, 2e-5, "staticcam rgb0")
+    with torch.no_grad():
+        plain = render(H, W, K, c2w=fixed.to(device), use_viewdirs=True, network_fine=mf, **kw)[0]
+    assert (plain - rgb).abs().max() > 1e-4, "the view directions of the other camera must matter"
+
+    with torch.no_grad():
+        rgb, disp, acc, ex = render(H, W, K, c2w=cam.to(device), use_viewdirs=True, network_fine=None, **kw)
+        o_c, _ = O.pixel_rays(H, W, K, cam)
+        want = O.render_chunks(O.pack_rays(o_c, d_c, 2.0, 6.0, use_viewdirs=True), 1 << 15, sd_coarse=sd_c, sd_fine=None, **okw)
+    close(rgb.reshape(-1, 3), want["rgb_map"], 2e-4, 2e-5, "network_fine=None rgb")
+    close(acc.reshape(-1), want["acc_map"], 2e-4, 2e-5, "network_fine=None acc")
+
+    # no view directions: 8-column ray records, output_linear head
+    sd_n = _peaky_out(O.random_state_dict(33, in_dirs=0, use_viewdirs=False, output_ch=5), 6.0, 1.0)
+    mn = _model(sd_n, device, use_viewdirs=False)
+    with torch.no_grad():
+        rgb, disp, acc, ex = render(H, W, K, c2w=cam.to(device), use_viewdirs=False, network_fine=mn,
+                                    **dict(kw, network_fn=mn))
+        want = O.render_chunks(O.pack_rays(o_c, d_c, 2.0, 6.0, use_viewdirs=False), 1 << 15, sd_coarse=sd_n, sd_fine=sd_n, **okw)
+    close(rgb.reshape(-1, 3), want["rgb_map"], 2e-4, 2e-5, "no-viewdirs rgb")
+    close(disp.reshape(-1), want["disp_map"], 1e-3, 1e-5, "no-viewdirs disp")
+    # ... and its train step: the fifth raw channel is carried along and gets a zero gradient
+    rgb, _, _, ex = render(H, W, K, c2w=cam.to(device), use_viewdirs=False, network_fine=mn, retraw=True, **dict(kw, network_fn=mn))
+    assert ex["raw"].shape == (H, W, 32 + 24, 5)
+    (rgb.square().mean() + ex["rgb0"].square().mean()).backward()
+    par = {k: v.clone().requires_grad_(True) for k, v in sd_n.items()}
+    want = O.render_chunks(O.pack_rays(o_c, d_c, 2.0, 6.0, use_viewdirs=False), 1 << 15, sd_coarse=par, sd_fine=par, **okw)
+    (want["rgb_map"].square().mean() + want["rgb0"].square().mean()).backward()
+    for k, p in mn.named_parameters():
+        if par[k].grad is None:       # views_linears exists in the module but takes no part without view directions
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        _grad_close(p.grad, par[k].grad, "no-viewdirs grad " + k, rtol=2e-3, atol_frac=1e-4)
+    assert float(mn.output_linear.weight.grad[4].abs().max()) == 0.0
+
+    # identity encoding: the network sees raw xyz and raw directions
+    e, ch = get_embedder(10, -1)
+    ed, chd = get_embedder(4, -1)
+    assert (ch, chd) == (3, 3)
+    sd_i = _peaky(O.random_state_dict(34, in_pts=3, in_dirs=3), 6.0, 1.0)
+    mi = NeRF(D=8, W=256, input_ch=3, input_ch_views=3, output_ch=5, skips=[4], use_viewdirs=True)
+    mi.load_state_dict(sd_i)
+    mi = mi.to(device)
+    qi = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=e, embeddirs_fn=ed, netchunk=1 << 16)
+    with torch.no_grad():
+        rgb = render(H, W, K, c2w=cam.to(device), use_viewdirs=True, network_fine=mi, **dict(kw, network_fn=mi, network_query_fn=qi))[0]
+        want = O.render_chunks(O.pack_rays(o_c, d_c, 2.0, 6.0, use_viewdirs=True), 1 << 15, sd_coarse=sd_i, sd_fine=sd_i,
+                               n_freq_pts=-1, n_freq_dirs=-1, **okw)
+    close(rgb.reshape(-1, 3), want["rgb_map"], 2e-4, 2e-5, "identity-encoding rgb")
 
 
 def test_create_nerf_checkpoint_roundtrip_and_render_path(device, tmp_path):
