@@ -223,17 +223,28 @@ def main():
     ap.add_argument("--no-bf16", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_VERBOSE"):   # where a hung multi-rank run is stuck: stacks of all threads after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_VERBOSE"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    # rehearsal aids for a one-GPU box: BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and BENCH_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the driver's runs set neither
+    if os.environ.get("BENCH_SINGLE_DEVICE"):
+        local = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from nerf_amd import ops
     from nerf_amd.run_nerf import render

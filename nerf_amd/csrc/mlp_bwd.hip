@@ -309,31 +309,44 @@ __device__ __forceinline__ void dw_loop(const DwTask& task, const WaveJob& job, 
     if constexpr (MODE == 2) b_off = (job.b_slot + (l32 >> 2)) * GS + (l32 & 3) + 4 * h;
     if (!a_live) a_off = 0;
 
-    auto compute = [&](const float* buf, int s_begin, int s_end, float (&csum)[4]) {
+    // Operands of step s are read one step ahead of the MFMAs that use them (the scheduler, left alone, issues each
+    // read right in front of its first use and parks the wave for the LDS latency sixteen times per chunk).
+    struct Operands { float a[4]; float b[2]; };
+    auto read_operands = [&](const float* buf, int s) {
+        Operands o{};
+        if constexpr (TM == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(buf + a_off + 8 * s);
+            o.a[0] = v[0]; o.a[1] = v[1]; o.a[2] = v[2]; o.a[3] = v[3];
+        } else if constexpr (TM == 1) {
+            const float v = buf[a_off + 8 * s];
+            o.a[0] = a_live ? v : 0.0f;
+        }
+        if constexpr (TN == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(buf + b_off + 8 * s);
+            o.b[0] = v.x; o.b[1] = v.y;
+        } else if constexpr (TN == 1) {
+            o.b[0] = buf[b_off + 8 * s];
+        }
+        return o;
+    };
+    // steps [s_begin, s_end) of the chunk in `buf`; `cur` holds the operands of s_begin on entry and those of s_end
+    // on exit (when s_end is still inside the chunk)
+    auto compute = [&](const float* buf, int s_begin, int s_end, Operands& cur, float (&csum)[4]) {
         if constexpr (MODE != 0) {
 #pragma unroll
             for (int s = s_begin; s < s_end; ++s) {
-                float a[4], b[2];
-                if constexpr (TM == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(buf + a_off + 8 * s);
-                    a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
-                } else {
-                    const float v = buf[a_off + 8 * s];
-                    a[0] = a_live ? v : 0.0f;
-                }
-                if constexpr (TN == 2) {
-                    const float2 v = *reinterpret_cast<const float2*>(buf + b_off + 8 * s);
-                    b[0] = v.x; b[1] = v.y;
-                } else {
-                    b[0] = buf[b_off + 8 * s];
-                }
+                Operands nxt = cur;
+                if (s + 1 < KT / 2) nxt = read_operands(buf, s + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < TM; ++e) csum[e] += a[e];
+                for (int e = 0; e < TM; ++e) csum[e] += cur.a[e];
 #pragma unroll
                 for (int e = 0; e < TM; ++e)
 #pragma unroll
                     for (int f = 0; f < TN; ++f)
-                        acc[e * TN + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[f], acc[e * TN + f], 0, 0, 0);
+                        acc[e * TN + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[e], cur.b[f], acc[e * TN + f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
         }
     };
@@ -347,12 +360,15 @@ __device__ __forceinline__ void dw_loop(const DwTask& task, const WaveJob& job, 
         const int buf = (int)((c - c0) & 1);
         const float* cur = smem + buf * (MAX_SLOTS * GS);
         float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        Operands ops{};
+        if constexpr (MODE != 0) ops = read_operands(cur, 0);
         issue(c + 1 < c1 ? c + 1 : c);          // in flight under the first half of this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink the loads to just above their stores)
-        compute(cur, 0, KT / 4, csum);          // (the last iteration re-stages its own chunk: no branch in the body)
+        compute(cur, 0, KT / 4, ops, csum);     // (the last iteration re-stages its own chunk: no branch in the body)
         __builtin_amdgcn_sched_barrier(0);
         commit(buf ^ 1);                        // the other buffer was last read before the previous barrier
-        compute(cur, KT / 4, KT / 2, csum);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur, KT / 4, KT / 2, ops, csum);
         if (want_bias) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) bsum[e] += csum[e];

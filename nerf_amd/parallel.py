@@ -37,6 +37,12 @@ def rank_world(group=None) -> Tuple[int, int]:
     return _world(group)
 
 
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """gloo moves host memory: device tensors go through a host copy on that backend (rehearsals of the multi-GPU
+    path on a box without RCCL peers); RCCL takes device tensors as they are."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Concatenate per-rank row blocks cut by shard_bounds (blocks differ by at most one row)."""
     rank, world = _world(group)
@@ -45,8 +51,13 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     rows = (n_total + world - 1) // world
     pad = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    out = torch.empty((world * rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    if _host_staged(pad, group):
+        pieces = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(world)]
+        dist.all_gather(pieces, pad.cpu(), group=group)
+        out = torch.cat(pieces, 0).to(local.device)
+    else:
+        out = torch.empty((world * rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
     parts = []
     for r in range(world):
         b, e = shard_bounds(n_total, r, world)
@@ -133,7 +144,12 @@ def allreduce_gradients(params: Iterable[torch.Tensor], group=None) -> None:
     if world == 1 or not params:
         return
     bucket = flatten_gradients(params)
-    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    if _host_staged(bucket, group):
+        host = bucket.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        bucket.copy_(host)
+    else:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     bucket.mul_(1.0 / world)
     unflatten_into_gradients(bucket, params)
 
