@@ -148,7 +148,17 @@ def pack_rays(rays_o, rays_d, near, far, viewdir_src=None, ndc=None):
     return out
 
 
+def _no_input_grad(t, what: str) -> None:
+    """The kernels differentiate with respect to the network parameters (and, in compositing, the raw network
+    outputs); an input that asks for a gradient would silently get none, so that is an error."""
+    if torch.is_tensor(t) and t.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError(f"{what} requires a gradient: the HIP render path has no backward with respect to "
+                                  "positions, directions or depths (upstream detaches them too: run_nerf.py:467)")
+
+
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, u: torch.Tensor, want_inds: bool = False):
+    _no_input_grad(bins, "sample_pdf: bins")
+    _no_input_grad(weights, "sample_pdf: weights (detach them, as run_nerf.py:467 does with the result)")
     bins, weights, u = _f32c(bins, "bins"), _f32c(weights, "weights"), _f32c(u, "u")
     n, nb = bins.shape
     assert weights.shape == (n, nb - 1), (bins.shape, weights.shape)
@@ -179,6 +189,7 @@ def sample_coarse(rays: torch.Tensor, t_vals: torch.Tensor, t_rand: Optional[tor
 
 
 def encode(x: torch.Tensor, n_freq: int) -> torch.Tensor:
+    _no_input_grad(x, "encode: x")
     x = _f32c(x, "x")
     assert x.shape[-1] == 3
     out = torch.empty(x.shape[:-1] + (3 + 6 * n_freq,), dtype=torch.float32, device=x.device)
@@ -264,6 +275,8 @@ def composite(raw, z, rays_d, noise=None, white_bkgd=False):
     rays_d: [n,3], any row stride (e.g. a column slice of the packed ray records).
     raw may carry more than 4 channels (output_ch = 5 without view directions): like run_nerf.py:323,333 only
     channels 0..3 are read, and the others receive a zero gradient."""
+    _no_input_grad(z, "composite: z")
+    _no_input_grad(rays_d, "composite: rays_d")
     if raw.shape[-1] > 4:
         raw = raw[..., :4]
     return _Composite.apply(raw, z, rays_d, noise, white_bkgd)
@@ -391,6 +404,8 @@ class _FusedMLP(torch.autograd.Function):
 
 def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_per_ray: int) -> torch.Tensor:
     params = list(model.parameters())
+    _no_input_grad(pts, "fused MLP: pts")
+    _no_input_grad(viewdirs, "fused MLP: viewdirs")
     # decided here, where the caller's grad mode is visible: under no_grad (rendering) nothing is saved
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     if not need_grad and getattr(model, "mlp_dtype", "f32") == "bf16" and pts_per_ray > 0:

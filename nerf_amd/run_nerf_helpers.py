@@ -148,10 +148,11 @@ class NeRF(nn.Module):
 
     def forward(self, x):
         """x: already-encoded inputs [..., input_ch + input_ch_views], as upstream (run_nerf_helpers.py:109-133).
-        The render path does not come through here (run_network fuses the encoding); gradients flow to the
-        parameters only."""
+        The render path does not come through here (run_network fuses the encoding).  The fused kernels give
+        gradients to the parameters only; an input that itself requires a gradient takes the layer-by-layer route,
+        whose autograd covers it."""
         x = ops.to_dev(x)
-        if not self.fused_arch():
+        if not self.fused_arch() or (torch.is_grad_enabled() and x.requires_grad):
             return self._forward_layers(x)
         out = ops.fused_mlp(x.reshape(-1, x.shape[-1]), None, self, 0)
         return out.reshape(list(x.shape[:-1]) + [out.shape[-1]])

@@ -657,6 +657,71 @@ def test_nerf_forward_on_encoded_inputs_and_generic_run_network(device):
         _grad_close(p.grad, params[k].grad, "encoded-entry grad " + k)
 
 
+def test_side_stream_and_graph_capture(device):
+    """Every entry point only enqueues on the caller's current stream: a render issued on a side stream, and one
+    captured into a HIP graph and replayed on new rays, give the bits of the plain call."""
+    from nerf_amd.run_nerf import render
+    mc = _model(_peaky(O.random_state_dict(31), 40.0), device)
+    mf = _model(_peaky(O.random_state_dict(32), 60.0), device)
+    kw = dict(network_fn=mc, network_query_fn=_query_fn(), N_samples=64, N_importance=128, network_fine=mf, perturb=0.0,
+              white_bkgd=True, use_viewdirs=True, ndc=False, near=2.0, far=6.0)
+    H = W = 40
+    K = np.array([[55.0, 0, 20.0], [0, 55.0, 20.0], [0, 0, 1]])
+
+    def rays_of(theta):
+        o, d = O.pixel_rays(H, W, K, O.orbit_pose(theta, -30.0, 4.0)[:3, :4])
+        return torch.stack([o.reshape(-1, 3), d.reshape(-1, 3)], 0).to(device)
+    r1, r2 = rays_of(10.0), rays_of(200.0)
+    with torch.no_grad():
+        want1 = render(H, W, K, chunk=1024, rays=r1, **kw)
+        want2 = render(H, W, K, chunk=1024, rays=r2, **kw)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            got1 = render(H, W, K, chunk=1024, rays=r1, **kw)
+        side.synchronize()
+        for a, b, what in zip(got1[:3], want1[:3], ("rgb", "disp", "acc")):
+            exact(a, b, "side stream " + what)
+
+        static = r1.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = render(H, W, K, chunk=1024, rays=static, **kw)
+        static.copy_(r2)
+        graph.replay()
+        torch.cuda.synchronize(device)
+        for a, b, what in zip(out[:3], want2[:3], ("rgb", "disp", "acc")):
+            exact(a, b, "graph replay " + what)
+        exact(out[3]["z_std"], want2[3]["z_std"], "graph replay z_std")
+
+
+def test_gradient_with_respect_to_inputs_is_never_silently_dropped(device):
+    """NeRF.forward(x) with x.requires_grad gives d/dx (layer-by-layer route, checked against the oracle); raw positions
+    that require a gradient are refused by the fused kernels and by the encoder instead of getting none."""
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import get_embedder
+    sd = O.random_state_dict(21)
+    m = _model(sd, device)
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = T(rng.normal(size=(50, 90)).astype(np.float32))
+    xg = x.to(device).requires_grad_(True)
+    m(xg).square().sum().backward()
+    xo = x.clone().requires_grad_(True)
+    par = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    O.mlp_apply(par, xo, 63, 27).square().sum().backward()
+    _grad_close(xg.grad, xo.grad, "d/dx of NeRF.forward", rtol=1e-3, atol_frac=1e-4)
+    for k, p in m.named_parameters():
+        _grad_close(p.grad, par[k].grad, "param grad on the d/dx route " + k, rtol=1e-3, atol_frac=1e-4)
+    pts = torch.zeros(8, 4, 3, device=device, requires_grad=True)
+    vd = torch.zeros(8, 3, device=device)
+    with pytest.raises(NotImplementedError):
+        m.query(pts.reshape(-1, 3), vd, 4)
+    with pytest.raises(NotImplementedError):
+        get_embedder(10, 0)[0](pts)
+    with torch.no_grad():
+        assert m.query(pts.reshape(-1, 3), vd, 4).shape == (32, 4)
+
+
 def test_other_network_shapes_run_layer_by_layer(device):
     """--netdepth / --netwidth / --multires other than the shipped configs: encoding kernel + library GEMMs, same
     numbers as the oracle, gradients included, through the same public entry points."""
