@@ -148,9 +148,10 @@ def hbm_kernels(prof):
                 "frac_of_hbm_peak": round(b / t / 1e9 / HBM_PEAK_GBS, 4)} for k, (b, t, c) in agg.items() if t > 0}
 
 
-def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
+def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=False):
     """The upstream optimisation step (run_nerf.py:826-883, no_batching mode) on synthetic targets: rays of one
-    400x400 view, n_rand random pixels, render with jitter, two MSE terms, backward, (all-reduce,) Adam, lr decay."""
+    400x400 view, n_rand random pixels, render with jitter, two MSE terms, backward, (all-reduce,) Adam, lr decay.
+    graphed: the same step recorded into HIP graphs after three eager steps and replayed (nerf_amd.graph_step)."""
     from nerf_amd import ops, parallel
     from nerf_amd.run_nerf import render
     from nerf_amd.run_nerf_helpers import get_rays, img2mse
@@ -159,11 +160,17 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
     kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
     params = list(models[0].parameters()) + list(models[1].parameters())
     saved = [p.detach().clone() for p in params]
-    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
+    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=graphed)
+    stepper = None
+    if graphed:
+        from nerf_amd.graph_step import GraphedTrainStep
+        stepper = GraphedTrainStep(H, W, K, kw, params, opt, n_rand, chunk=1024 * 32, eager_steps=3,
+                                   between=(lambda: parallel.allreduce_gradients(params)) if world > 1 else None)
+        warmup = max(warmup, 5)    # three eager steps, the recording, one replay
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     thetas = np.linspace(-180, 180, 41)[:-1]
-    poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(warmup + steps)]
+    poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(max(warmup, 5) + steps)]
     target_img = torch.rand(H * W, 3, device=dev, generator=gen)
 
     def one(i):
@@ -171,6 +178,9 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
         sel = torch.randperm(H * W, device=dev, generator=gen)[:n_rand]
         batch_rays = torch.stack([rays_o.reshape(-1, 3)[sel], rays_d.reshape(-1, 3)[sel]], 0)
         target = target_img[sel]
+        if stepper is not None:
+            stepper.set_lr(5e-4 * (0.1 ** (i / (500 * 1000))))
+            return stepper.step(batch_rays, target)
         rgb, disp, acc, extras = render(H, W, K, chunk=1024 * 32, rays=batch_rays, verbose=False, retraw=True, **kw)
         opt.zero_grad()
         loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
@@ -184,7 +194,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
 
     for i in range(warmup):
         one(i)
-    ops.PROFILE = []
+    ops.PROFILE = None if graphed else []     # events recorded inside a graph cannot be timed
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -203,6 +213,12 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed):
     with torch.no_grad():
         for p, s0 in zip(params, saved):
             p.copy_(s0)
+    for m in models:
+        m._pack_key = None
+    if graphed:
+        return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
+                "n_rand_per_gpu": n_rand, "steps": steps, "final_loss": float(loss),
+                "note": "the same step replayed from two HIP graphs (render+loss+backward | Adam)"}
     kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in ("mlp_fwd_save", "mlp_bwd"))
     flop = n_rand * 256 * FLOP_PER_POINT_TRAIN * steps
     return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "n_rand_per_gpu": n_rand,
@@ -360,6 +376,11 @@ def main():
         # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)
         out["train"] = time_train(models, kwargs, dev, world, 1024, 10, 3, seed=1234 + rank)
         out["train_8192"] = time_train(models, kwargs, dev, world, 8192, 4, 2, seed=4321 + rank)
+        if world == 1:   # single-GPU extra; the multi-rank runs keep to the eager step
+            try:
+                out["train_graphed"] = time_train(models, kwargs, dev, world, 1024, 10, 5, seed=1234 + rank, graphed=True)
+            except Exception as exc:  # the eager numbers above stand without it
+                out["train_graphed"] = {"error": repr(exc)}
 
     if rank == 0:
         if args.cpu_rays > 0 and world == 1:   # the CPU leg is a single-GPU-run extra: ranks of a multi-GPU run do not wait for it
