@@ -71,24 +71,44 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
     __syncthreads();
     st.fetch(0);
 
-    f32x16 A[8], B[8];
+    // Gradient tiles ping-pong between two arrays: a layer reads one and accumulates W^T dY into the other.
+    f32x16 P[8], Q[8];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    // ReLU mask of masked layer m as the forward left it: bit 16 (t % 2) + r of dword t / 2 <-> register r of tile t
-    auto mask_word = [&](int m) { return *reinterpret_cast<const u32x4*>(at + act_mask_offset(VIEWDIRS ? 1 : 0, m, wave, lane)); };
-    auto on = [](const u32x4& mw, int t, int r) { return ((mw[t >> 1] >> (16 * (t & 1) + r)) & 1u) != 0u; };
-    float d_sigma = 0.0f;
-    int first_layer;  // the pts layer whose output gradient the first 256x256 section produces
+    auto inP = [&]<int ti>() -> const f32x16& { return P[ti]; };
+    auto inQ = [&]<int ti>() -> const f32x16& { return Q[ti]; };
+    // ReLU mask of masked layer m as the forward left it: bit 16 (t % 2) + r of dword t / 2 <-> register r of tile t.
+    // Requested right before the layer that uses it from its second tile on: the first tile's MFMAs hide the latency.
+    uint32_t mk[4] = {0u, 0u, 0u, 0u};
+    auto load_mask = [&](int m) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(at + act_mask_offset(VIEWDIRS ? 1 : 0, m, wave, lane));
+        mk[0] = w[0]; mk[1] = w[1]; mk[2] = w[2]; mk[3] = w[3];
+    };
+    auto on = [&](int t, int r) { return ((mk[t >> 1] >> (16 * (t & 1) + r)) & 1u) != 0u; };
+    // A layer's input (the dY of the layer above) goes to the workspace while the layer multiplies: one 16-byte
+    // store behind every other weight block of the second half of each output tile.
+    float* srows = nullptr;
+    auto store_quad = [&]<int T, int I>(const f32x16& a) {
+        const f32x4 v = {a[4 * I], a[4 * I + 1], a[4 * I + 2], a[4 * I + 3]};
+        *reinterpret_cast<f32x4*>(srows + (8 * T + 2 * I) * GROUP_FLOATS + lane_off) = v;
+    };
+    auto saveP = [&]<int TO, int BI>() {
+        if constexpr (BI >= 16 && BI < 24 && (BI & 1) == 0) store_quad.template operator()<TO, (BI - 16) / 2>(P[TO]);
+    };
+    auto saveQ = [&]<int TO, int BI>() {
+        if constexpr (BI >= 16 && BI < 24 && (BI & 1) == 0) store_quad.template operator()<TO, (BI - 16) / 2>(Q[TO]);
+    };
+
     if constexpr (VIEWDIRS) {
         f32x4 g = {0, 0, 0, 0};
         if (valid) g = *reinterpret_cast<const f32x4*>(d_out + p * 4);
-        d_sigma = g[3];
+        const float d_sigma = g[3];
         if (h == 0) {   // head operands of the weight-gradient GEMM: one row group each, zero padded
             const f32x4 ga = {g[0], g[1], g[2], 0.0f}, gb = {g[3], 0.0f, 0.0f, 0.0f};
             *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD) + pw * 4) = ga;
             *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD2) + pw * 4) = gb;
         }
-        // views layer: d(hidden) = Wrgb^T d_rgb, masked by the saved post-ReLU activations
-        const u32x4 mv = mask_word(8);
+        // views layer: d(hidden) = Wrgb^T d_rgb, masked by the saved post-ReLU activations -> P[0..3]
+        load_mask(8);
         const float* wrgb = aux + AUX_HEAD + 256;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -100,18 +120,21 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = fmaf(w2[e], g[2], fmaf(w1[e], g[1], w0[e] * g[0]));
-                    A[t][4 * i + e] = on(mv, t, 4 * i + e) ? v : 0.0f;
+                    P[t][4 * i + e] = on(t, 4 * i + e) ? v : 0.0f;
                 }
             }
-        store_tiles<4>(A, rows_of(st_, SCR_VIEWS), lane_off);
-        // d(feature) = Wviews[:, :256]^T dY_views; feature_linear has no activation
-        run_section<8, 4, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return A[ti]; });
-#pragma unroll
-        for (int t = 0; t < 8; ++t) A[t] = B[t];
-        store_tiles<8>(A, rows_of(st_, SCR_FEAT), lane_off);
-        first_layer = 7;
+        // d(feature) = Wviews[:, :256]^T dY_views -> Q; feature_linear has no activation.  Eight output tiles read
+        // four input tiles: two stores of the views dY per output tile.
+        srows = rows_of(st_, SCR_VIEWS);
+        run_layer_bwd<8, 4, false, false>(st, lane, Q, inP, nullptr, 0.0f, mk, [&]<int TO, int BI>() {
+            if constexpr (BI == 8 || BI == 12) store_quad.template operator()<TO / 2, 2 * (TO & 1) + (BI - 8) / 4>(P[TO / 2]);
+        });
+        // d(h7) = Wfeature^T d(feature) + Walpha^T d_sigma, masked -> P
+        load_mask(7);
+        srows = rows_of(st_, SCR_FEAT);
+        run_layer_bwd<8, 8, true, true>(st, lane, P, inQ, aux + AUX_HEAD + h * 16, d_sigma, mk, saveQ);
     } else {
-        // d(h7) = Wout^T d_out
+        // d(h7) = Wout^T d_out, masked -> P
         float g[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) g[c] = (valid && c < output_ch) ? d_out[p * output_ch + c] : 0.0f;
@@ -120,41 +143,31 @@ k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, co
             *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD) + pw * 4) = ga;
             *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD + 4) + pw * 4) = gb;
         }
-        const u32x4 m7 = mask_word(7);
+        load_mask(7);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = 0.0f;
                 for (int c = 0; c < output_ch; ++c) v = fmaf(aux[AUX_HEAD + c * 256 + t * 32 + h * 16 + r], g[c], v);
-                A[t][r] = on(m7, t, r) ? v : 0.0f;
+                P[t][r] = on(t, r) ? v : 0.0f;
             }
-        store_tiles<8>(A, rows_of(st_, SCR_H0 + 7 * 256), lane_off);
-        first_layer = 6;
     }
 
+    // dY of pts layers 6 .. 1, two per trip: P (dY of layer l + 1) -> Q (layer l) -> P (layer l - 1)
 #pragma unroll 1
-    for (int l = first_layer; l >= 0; --l) {
-        // ReLU mask of pts layer l, requested before the matrix work that hides its latency
-        const u32x4 ml = mask_word(l);
-        run_section<8, 8, false>(st, lane, B, [&]<int ti>() -> const f32x16& { return A[ti]; });
-        if (VIEWDIRS && l == 7) {
-            const float* wa = aux + AUX_HEAD;
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(wa + t * 32 + h * 16 + 4 * i);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) B[t][4 * i + e] = fmaf(w[e], d_sigma, B[t][4 * i + e]);
-                }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) A[t][r] = on(ml, t, r) ? B[t][r] : 0.0f;
-        store_tiles<8>(A, rows_of(st_, SCR_H0 + 256 * l), lane_off);
+    for (int l = 6; l > 0; l -= 2) {
+        load_mask(l);
+        srows = rows_of(st_, SCR_H0 + 256 * (l + 1));
+        run_layer_bwd<8, 8, true, false>(st, lane, Q, inP, nullptr, 0.0f, mk, saveP);
+        load_mask(l - 1);
+        srows = rows_of(st_, SCR_H0 + 256 * l);
+        run_layer_bwd<8, 8, true, false>(st, lane, P, inQ, nullptr, 0.0f, mk, saveQ);
     }
+    load_mask(0);
+    srows = rows_of(st_, SCR_H0 + 256);
+    run_layer_bwd<8, 8, true, false>(st, lane, Q, inP, nullptr, 0.0f, mk, saveP);
+    store_tiles<8>(Q, rows_of(st_, SCR_H0), lane_off);
 }
 
 // ------------------------------------------------------------------------------------------------
