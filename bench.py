@@ -234,7 +234,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=800, help="image side; 800 is the benchmark configuration")
-    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=16384, help="rays in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-bf16", action="store_true")
     args = ap.parse_args()
