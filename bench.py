@@ -350,9 +350,11 @@ def main():
             from nerf_amd import parallel
             from nerf_amd.run_nerf_helpers import get_rays
 
+            shared_poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(n_views)]   # the same view on every rank
+
             def frame(i):
                 with torch.no_grad():
-                    o, d = get_rays(H, W, K, poses[i])
+                    o, d = get_rays(H, W, K, shared_poses[i])
                     return parallel.render_sharded(H, W, K, chunk, (o, d), **kwargs)
             frame(0)
             sync()
