@@ -153,3 +153,28 @@ def test_product_path_has_no_cpu_fallback():
     from nerf_amd.run_nerf_helpers import get_rays
     with pytest.raises(RuntimeError):
         get_rays(4, 4, np.array([[4., 0, 2], [0, 4., 2], [0, 0, 1]]), torch.eye(4)[:3])
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line committed with the profiles carries every field the driver reads, with consistent arithmetic."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.load(open(os.path.join(root, "profiles", "r1_bench.json")))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert line["metric"] == base["metric"] and line["unit"] == "rays/s"
+    for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert "model" not in line["config"]
+    # value = rays of the timed steps / time
+    rays = line["config"]["rays_per_step_per_gpu"] * line["n_gpus"]
+    assert abs(line["value"] - rays / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
