@@ -22,21 +22,51 @@ struct Sample {
     float z, dist, sig, alpha, keep;  // keep = 1 - alpha + 1e-10 as fp32
 };
 
-__device__ __forceinline__ Sample load_sample(const float* __restrict__ raw, const float* __restrict__ z,
-                                              const float* __restrict__ noise, int64_t base, int s, int S, float dnorm) {
+// Lane i of a tile holds sample s = s0 + i.  What a lane reads from memory for one tile ...
+struct Loaded {
+    float4 raw;
+    float z, z_tile, nz;   // z_tile: first depth of the next tile (one address for the whole wave)
+};
+__device__ __forceinline__ Loaded fetch_tile(const float* __restrict__ raw, const float* __restrict__ z,
+                                             const float* __restrict__ noise, int64_t base, int s0, int lane, int S) {
+    const int s = s0 + lane;
+    const bool live = s < S;
+    Loaded f;
+    f.raw = live ? reinterpret_cast<const float4*>(raw)[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    f.z = live ? z[base + s] : 0.0f;
+    f.z_tile = (s0 + 64 < S) ? z[base + s0 + 64] : 0.0f;
+    f.nz = live && noise ? noise[base + s] : 0.0f;
+    return f;
+}
+// ... and what it derives from that.  The gap to the next depth comes from the neighbouring lane (wave_shl:1); the
+// last lane takes the first depth of the next tile.
+__device__ __forceinline__ Sample make_sample(const Loaded& f, bool with_noise, int s0, int lane, int S, float dnorm) {
+    const int s = s0 + lane;
     Sample q;
-    q.raw = reinterpret_cast<const float4*>(raw)[base + s];
-    q.z = z[base + s];
-    const float gap = (s < S - 1) ? (z[base + s + 1] - q.z) : 1e10f;
+    q.raw = f.raw;
+    q.z = f.z;
+    // wave_shl:1 -- lane i receives lane i + 1, lane 63 keeps `old`
+    const float z_next = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(f.z_tile), __float_as_int(f.z), 0x130, 0xf, 0xf, false));
+    const float gap = (s < S - 1) ? (z_next - q.z) : 1e10f;
     q.dist = gap * dnorm;
-    q.sig = noise ? (q.raw.w + noise[base + s]) : q.raw.w;
+    q.sig = with_noise ? (q.raw.w + f.nz) : q.raw.w;
     const float act = q.sig > 0.0f ? q.sig : (q.sig != q.sig ? q.sig : 0.0f);  // relu, NaN kept
     q.alpha = 1.0f - expf(-act * q.dist);
-    q.keep = (1.0f - q.alpha) + 1e-10f;
+    q.keep = s < S ? (1.0f - q.alpha) + 1e-10f : 1.0f;
     return q;
 }
+__device__ __forceinline__ Sample load_sample(const float* __restrict__ raw, const float* __restrict__ z,
+                                              const float* __restrict__ noise, int64_t base, int s0, int lane, int S,
+                                              float dnorm) {
+    return make_sample(fetch_tile(raw, z, noise, base, s0, lane, S), noise != nullptr, s0, lane, S, dnorm);
+}
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Colour sigmoid on the hardware exp2 / reciprocal: within 3 ulp of the correctly rounded value over the whole
+// range (saturating to 0 and 1 like it), four instructions instead of two dozen.  The density term above keeps the
+// accurate expf: its error is raised to the power of the sample count by the transmittance product.
+__device__ __forceinline__ float sigmoidf(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
 
 __device__ __forceinline__ float ray_norm(const float* rr) {
     const float dx = rr[0], dy = rr[1], dz = rr[2];
@@ -51,20 +81,46 @@ k_composite_fwd(int64_t n, int S, const float* __restrict__ raw, const float* __
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
-    for (int64_t ray = wave0; ray < n; ray += nwaves) {
-        const float dnorm = ray_norm(rays + ray * ld);
-        const int64_t base = ray * S;
-        double carry = 1.0;  // product of keep over all earlier tiles
-        float sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;   // this lane's share of the ray sums (fp32, like the reference's)
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            const int s = s0 + lane;
-            const bool live = s < S;
-            Sample q;
-            double keep = 1.0;
-            if (live) {
-                q = load_sample(raw, z, noise, base, s, S, dnorm);
-                keep = (double)q.keep;
+    // The work of a wave is a sequence of (ray, tile) items; the loads of the next item are issued before the
+    // arithmetic of the current one, so two tiles per wave are in flight.
+    const int ntiles = (S + 63) / 64;
+    int64_t ray = wave0;
+    int t = 0;
+    Loaded cur{};
+    float3 dir = make_float3(0.f, 0.f, 0.f);
+    if (ray < n) {
+        cur = fetch_tile(raw, z, noise, ray * S, 0, lane, S);
+        const float* rr = rays + ray * ld;
+        dir = make_float3(rr[0], rr[1], rr[2]);
+    }
+    double carry = 1.0;  // product of keep over all earlier tiles of the ray
+    float sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;   // this lane's share of the ray sums (fp32, like the reference's)
+    float dnorm = 0.0f;
+    while (ray < n) {
+        int64_t nray = ray;
+        int nt = t + 1;
+        if (nt == ntiles) { nt = 0; nray = ray + nwaves; }
+        Loaded nxt{};
+        float3 ndir = dir;
+        if (nray < n) {
+            nxt = fetch_tile(raw, z, noise, nray * S, nt * 64, lane, S);
+            if (nt == 0) {
+                const float* rr = rays + nray * ld;
+                ndir = make_float3(rr[0], rr[1], rr[2]);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t base = ray * S;
+        if (t == 0) {
+            dnorm = sqrtf((dir.x * dir.x + dir.y * dir.y) + dir.z * dir.z);
+            carry = 1.0;
+            sr = sg = sb = sd = sa = 0.0f;
+        }
+        {
+            const int s = t * 64 + lane;
+            const bool live = s < S;
+            const Sample q = make_sample(cur, noise != nullptr, t * 64, lane, S, dnorm);
+            const double keep = (double)q.keep;
             const double incl = wave_scan_f64<OpMul>(keep);
             const double excl = dpp_f64<0x138, 0xf, 0xf>(1.0, incl);   // wave_shr:1, lane 0 keeps the identity
             const float T = (float)(carry * excl);
@@ -80,20 +136,22 @@ k_composite_fwd(int64_t n, int S, const float* __restrict__ raw, const float* __
                 sa = sa + w;
             }
         }
-        sr = wave_sum_f32(sr); sg = wave_sum_f32(sg); sb = wave_sum_f32(sb); sd = wave_sum_f32(sd); sa = wave_sum_f32(sa);
-        if (lane == 0) {
-            const float a = sa, d = sd;
-            float r = sr, g = sg, b = sb;
-            if (white) {
-                const float bg = 1.0f - a;
-                r = r + bg; g = g + bg; b = b + bg;
+        if (t == ntiles - 1) {
+            const float a = wave_sum_f32(sa), d = wave_sum_f32(sd);
+            float r = wave_sum_f32(sr), g = wave_sum_f32(sg), b = wave_sum_f32(sb);
+            if (lane == 0) {
+                if (white) {
+                    const float bg = 1.0f - a;
+                    r = r + bg; g = g + bg; b = b + bg;
+                }
+                rgb[ray * 3 + 0] = r; rgb[ray * 3 + 1] = g; rgb[ray * 3 + 2] = b;
+                acc[ray] = a;
+                depth[ray] = d;
+                const float q = d / a;
+                disp[ray] = 1.0f / ((q != q) ? q : (q > 1e-10f ? q : 1e-10f));
             }
-            rgb[ray * 3 + 0] = r; rgb[ray * 3 + 1] = g; rgb[ray * 3 + 2] = b;
-            acc[ray] = a;
-            depth[ray] = d;
-            const float q = d / a;
-            disp[ray] = 1.0f / ((q != q) ? q : (q > 1e-10f ? q : 1e-10f));
         }
+        cur = nxt; dir = ndir; ray = nray; t = nt;
     }
 }
 
@@ -142,9 +200,7 @@ k_composite_bwd(int64_t n, int S, const float* __restrict__ raw, const float* __
             for (int t = 0; t < ntiles; ++t) {
                 if (lane == 0) carry_in[t] = carry;
                 if (t == ntiles - 1) break;
-                const int s = t * 64 + lane;
-                double keep = 1.0;
-                if (s < S) keep = (double)load_sample(raw, z, noise, base, s, S, dnorm).keep;
+                const double keep = (double)load_sample(raw, z, noise, base, t * 64, lane, S, dnorm).keep;
                 carry *= wave_reduce_f64<OpMul>(keep);
             }
         }
@@ -153,12 +209,10 @@ k_composite_bwd(int64_t n, int S, const float* __restrict__ raw, const float* __
         for (int t = ntiles - 1; t >= 0; --t) {
             const int s = t * 64 + lane;
             const bool live = s < S;
-            Sample q;
+            const Sample q = load_sample(raw, z, noise, base, t * 64, lane, S, dnorm);
             float w = 0.0f, G = 0.0f, sr = 0, sg = 0, sb = 0;
-            double keep = 1.0;
+            const double keep = (double)q.keep;
             if (live) {
-                q = load_sample(raw, z, noise, base, s, S, dnorm);
-                keep = (double)q.keep;
                 w = weights[base + s];
                 sr = sigmoidf(q.raw.x); sg = sigmoidf(q.raw.y); sb = sigmoidf(q.raw.z);
                 G = (((gr * sr + gg * sg) + gb * sb) + gd * q.z) + ga;

@@ -48,20 +48,22 @@ __device__ __forceinline__ double wave_scan_f64(double v) {
 }
 
 // fp32 sum over all 64 lanes, returned in every lane: a balanced tree (row_shr 1/2/4/8 inside rows of 16, then the
-// row totals), rounding error <= 6 half-ulps of the sum of magnitudes.  The shifted-in value of a lane without a
-// source is 0 (bound_ctrl), so after the row steps lane 15 of each row holds the row total.
+// row totals pairwise: rows 1 and 3 take the totals of rows 0 and 2, rows 2 and 3 the sum of rows 0 and 1, so lane 63
+// ends with (r3 + r2) + (r1 + r0)), rounding error <= 6 half-ulps of the sum of magnitudes.  A lane without a source
+// receives 0.
 __device__ __forceinline__ float wave_sum_f32(float v) {
-    auto shr = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+    auto from = [](float x, auto ctrl, auto rows, auto bound) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xf,
+                                                          decltype(bound)::value));
     };
-    v += shr(v, std::integral_constant<int, 0x111>{});
-    v += shr(v, std::integral_constant<int, 0x112>{});
-    v += shr(v, std::integral_constant<int, 0x114>{});
-    v += shr(v, std::integral_constant<int, 0x118>{});
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)) +
-           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)) +
-           (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47)) +
-            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)));
+    using std::integral_constant;
+    v += from(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, std::true_type{});
+    v += from(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, std::true_type{});
+    v += from(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, std::true_type{});
+    v += from(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, std::true_type{});
+    v += from(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, std::false_type{});   // row_bcast:15
+    v += from(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, std::false_type{});   // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // op over all 64 lanes, returned in every lane (wave-uniform)
