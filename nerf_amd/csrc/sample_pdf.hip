@@ -84,6 +84,28 @@ __host__ __device__ inline int pow2_at_least(int n) {
     return p;
 }
 
+__host__ __device__ inline int pow2_at_most(int n) {
+    int p = 1;
+    while (2 * p <= n) p <<= 1;
+    return p;
+}
+
+// Length of the longest prefix of an ordered list of L >= 1 items whose items all satisfy `holds(index)`, for a
+// condition that is true on a prefix and false after it.  A fixed number of halving steps (floor(log2 L) + 1) with no
+// lane-dependent control flow: every lane probes in every step, a probe past the end re-reads the last item and is
+// ignored.
+template <typename Holds>
+__device__ __forceinline__ int prefix_length(int L, Holds holds) {
+    int pos = 0;
+    for (int step = pow2_at_most(L); step >= 1; step >>= 1) {
+        const int probe = pos + step;
+        const bool inside = probe <= L;
+        const bool ok = holds((inside ? probe : L) - 1);
+        pos = (inside && ok) ? probe : pos;
+    }
+    return pos;
+}
+
 // keys[i] = (order key << 32) | index for i < count, all-ones padding up to P; returns whether the list is ordered
 __device__ __forceinline__ bool build_keys(uint64_t* keys, const float* vals, int first_index, int count, int P, int lane) {
     for (int i = lane; i < P; i += 64)
@@ -107,8 +129,11 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* a, int P, int lane) {
         }
 }
 
+// SC, SI > 0: the sample counts as compile-time constants (the shipped configurations: every loop unrolls and the
+// trip counts, LDS offsets and search depths fold); SC = 0: taken from the arguments.
+template <int SC, int SI>
 __global__ void __launch_bounds__(WAVE * WAVES_PER_BLOCK)
-k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict__ z,
+k_sample_fine(int64_t n, int Sc_arg, int Si_arg, int bins_given, const float* __restrict__ z,
               const float* __restrict__ weights, const float* __restrict__ u, int u_shared,
               const float* __restrict__ rays, int ld,
               float* __restrict__ z_out, float* __restrict__ pts_out, float* __restrict__ z_std,
@@ -116,6 +141,7 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
+    const int Sc = SC > 0 ? SC : Sc_arg, Si = SC > 0 ? SI : Si_arg;
     const int Sf = Sc + Si, nb = Sc - 1, nw = Sc - 2;
     const int Sf4 = (Sf + 3) & ~3, nb4 = (nb + 3) & ~3;
     float* zs = smem + (size_t)wv * (2 * Sf4 + 3 * nb4);  // merged (unsorted) depths
@@ -128,6 +154,7 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
     uint64_t* ks = kc + Pc;       // (order key, index) of the coarse / fine depths
     const int64_t wave0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
     const int64_t nwaves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const double inv_si = 1.0 / (double)Si;
     for (int64_t ray = wave0; ray < n; ray += nwaves) {
         // ---- stage inputs
         if (bins_given) {  // stand-alone sample_pdf: z holds the nb bin edges, weights the nw = nb-1 bin weights
@@ -148,7 +175,7 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
             float fin = 0.0f;
             for (int e = vec * 8; e < nw; ++e) fin = fin + wp[e];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) fin = fin + __shfl(part, k, 64);
+            for (int k = 0; k < 8; ++k) fin = fin + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), k));
             total = fin;
         } else {
             total = cascade_row_sum(wp, 1, 0, nw);
@@ -170,11 +197,7 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
         double su = 0.0;
         for (int j = lane; j < Si; j += 64) {
             const float uj = u_shared ? u[j] : u[ray * Si + j];
-            int lo = 0, hi = nb;  // first index with cdf[idx] > uj
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (cdf[mid] > uj) hi = mid; else lo = mid + 1;
-            }
+            const int lo = prefix_length(nb, [&](int k) { return !(cdf[k] > uj); });  // first index with cdf[idx] > uj
             const int below = lo - 1 > 0 ? lo - 1 : 0;
             const int above = lo < nb - 1 ? lo : nb - 1;
             const float cb = cdf[below], ca = cdf[above];
@@ -191,45 +214,60 @@ k_sample_fine(int64_t n, int Sc, int Si, int bins_given, const float* __restrict
         __builtin_amdgcn_wave_barrier();
         // ---- population standard deviation of the new samples
         if (z_std) {
-            const double mean = wave_sum_d(su) / (double)Si;
+            const double mean = wave_sum_d(su) * inv_si;
             double m2 = 0.0;
             for (int j = lane; j < Si; j += 64) {
                 const double dv = (double)zs[Sc + j] - mean;
                 m2 += dv * dv;
             }
             m2 = wave_sum_d(m2);
-            if (lane == 0) z_std[ray] = (float)sqrt(m2 / (double)Si);
+            // (the fp64 mean square is rounded once and its root taken in fp32: within an ulp of the fp64 root, a
+            // tenth of the instructions; the reference works in fp32 throughout)
+            if (lane == 0) z_std[ray] = sqrtf((float)(m2 * inv_si));
         }
         if (bins_given) { __builtin_amdgcn_wave_barrier(); continue; }
         // ---- sort(cat(coarse, fine)): order each list if it is not ordered yet, then merge by rank
+        // Both lists already in order and free of NaN (every deterministic render): the ranks come from float
+        // comparisons on the depths themselves -- no keys, 4-byte reads.  -0 == +0 in both formulations.
+        bool ordered = true;
+        for (int i = lane; i + 1 < Sc; i += 64) ordered = ordered && (zs[i] <= zs[i + 1]);
+        for (int i = lane; i + 1 < Si; i += 64) ordered = ordered && (zs[Sc + i] <= zs[Sc + i + 1]);
+        if (lane == 0) ordered = ordered && (zs[Sc - 1] == zs[Sc - 1]) && (zs[Sf - 1] == zs[Sf - 1]);   // lone elements
+        if (__all(ordered)) {
+            for (int i = lane; i < Sc; i += 64) {   // a coarse depth follows the fine depths strictly below it
+                const float me = zs[i];
+                zsorted[i + prefix_length(Si, [&](int k) { return zs[Sc + k] < me; })] = me;
+            }
+            for (int j = lane; j < Si; j += 64) {   // a fine depth follows the coarse depths below or equal
+                const float me = zs[Sc + j];
+                zsorted[j + prefix_length(Sc, [&](int k) { return zs[k] <= me; })] = me;
+            }
+        } else {
         if (!build_keys(kc, zs, 0, Sc, Pc, lane)) bitonic_sort(kc, Pc, lane);
         if (!build_keys(ks, zs + Sc, Sc, Si, Ps, lane)) bitonic_sort(ks, Ps, lane);
         __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < Sf; e += 64) {
-            const bool coarse = e < Sc;
-            const uint64_t me = coarse ? kc[e] : ks[e - Sc];
+        for (int i = lane; i < Sc; i += 64) {
+            const uint64_t me = kc[i];
             const uint32_t key = (uint32_t)(me >> 32);
-            // coarse: fine elements strictly below;  fine: coarse elements below or equal
-            const uint64_t* other = coarse ? ks : kc;
-            int lo = 0, hi = coarse ? Si : Sc;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const uint32_t ok = (uint32_t)(other[mid] >> 32);
-                if (coarse ? (ok < key) : (ok <= key)) lo = mid + 1; else hi = mid;
-            }
-            zsorted[(coarse ? e : e - Sc) + lo] = zs[(uint32_t)me];
+            zsorted[i + prefix_length(Si, [&](int k) { return (uint32_t)(ks[k] >> 32) < key; })] = zs[(uint32_t)me];
+        }
+        for (int j = lane; j < Si; j += 64) {
+            const uint64_t me = ks[j];
+            const uint32_t key = (uint32_t)(me >> 32);
+            zsorted[j + prefix_length(Sc, [&](int k) { return (uint32_t)(kc[k] >> 32) <= key; })] = zs[(uint32_t)me];
+        }
         }
         __builtin_amdgcn_wave_barrier();
         for (int s = lane; s < Sf; s += 64) z_out[ray * Sf + s] = zsorted[s];
         if (pts_out) {
             const float* rr = rays + ray * ld;
             const float ox = rr[0], oy = rr[1], oz = rr[2], dx = rr[3], dy = rr[4], dz = rr[5];
-            for (int e = lane; e < Sf * 3; e += 64) {
-                const int s = e / 3, c = e - s * 3;
+            float* po = pts_out + ray * Sf * 3;
+            for (int s = lane; s < Sf; s += 64) {   // three stores of stride 12 bytes; the cache merges them into full lines
                 const float zz = zsorted[s];
-                const float o = c == 0 ? ox : (c == 1 ? oy : oz);
-                const float d = c == 0 ? dx : (c == 1 ? dy : dz);
-                pts_out[ray * Sf * 3 + e] = o + d * zz;
+                po[3 * s + 0] = ox + dx * zz;
+                po[3 * s + 1] = oy + dy * zz;
+                po[3 * s + 2] = oz + dz * zz;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -253,15 +291,20 @@ int nerf_sample_fine(int64_t n, int Sc, int Si, const float* z, const float* wei
                                                   (size_t)(pow2_at_least(Sc) + pow2_at_least(Si)) * sizeof(uint64_t));
     NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_fine: Sc+Si=%d needs %zu bytes of LDS (> 160 KiB)", Sc + Si, lds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine<0, 0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_sample_fine: LDS attribute: %s", hipGetErrorString(e));
     }
     int64_t g = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     const int64_t cap = 256 * 8;
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(k_sample_fine, dim3((int)g), dim3(WAVE * WAVES_PER_BLOCK), lds, as_stream(stream), n, Sc, Si, 0, z,
-                       weights, u, u_shared, rays, ray_stride, z_out, pts_out, z_std, samples, inds);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((int)g), dim3(WAVE * WAVES_PER_BLOCK), lds, as_stream(stream), n, Sc, Si, 0, z,
+                           weights, u, u_shared, rays, ray_stride, z_out, pts_out, z_std, samples, inds);
+    };
+    if (Sc == 64 && Si == 128) go(k_sample_fine<64, 128>);
+    else if (Sc == 64 && Si == 64) go(k_sample_fine<64, 64>);
+    else go(k_sample_fine<0, 0>);
     return launched("nerf_sample_fine");
 }
 
@@ -277,14 +320,14 @@ int nerf_sample_pdf(int64_t n, int n_bins, int Si, const float* bins, const floa
                                                   (size_t)(pow2_at_least(Sc) + pow2_at_least(Si)) * sizeof(uint64_t));
     NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_pdf: n_bins+Si=%d needs %zu bytes of LDS (> 160 KiB)", n_bins + Si, lds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine<0, 0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_sample_pdf: LDS attribute: %s", hipGetErrorString(e));
     }
     int64_t g = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     const int64_t cap = 256 * 8;
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(k_sample_fine, dim3((int)g), dim3(WAVE * WAVES_PER_BLOCK), lds, as_stream(stream), n, Sc, Si, 1,
+    hipLaunchKernelGGL((k_sample_fine<0, 0>), dim3((int)g), dim3(WAVE * WAVES_PER_BLOCK), lds, as_stream(stream), n, Sc, Si, 1,
                        bins, weights, u, u_shared, nullptr, 0, nullptr, nullptr, nullptr, samples, inds);
     return launched("nerf_sample_pdf");
 }
