@@ -193,3 +193,60 @@ def test_graphed_train_step_matches_eager(device):
         ra = render(H, W, K, chunk=1 << 15, rays=batches[0][0], **kw_a)[0]
         rb = render(H, W, K, chunk=1 << 15, rays=batches[0][0], **kw_b)[0]
     assert torch.equal(ra, rb), "a render after replays must use the weights of the last step"
+
+
+def test_optimisation_recovers_a_teacher_scene(device):
+    """End to end: images rendered from one pair of networks are the training targets of another pair started from
+    different weights; 250 steps of the upstream loop (jittered samples, both losses, Adam) must cut the loss several
+    times over and raise the PSNR -- a check of the gradient path as a whole that per-step parity cannot give."""
+    from nerf_amd.raybatch import ViewSampler
+    from nerf_amd.run_nerf import render, run_network
+    from nerf_amd.run_nerf_helpers import NeRF, get_embedder, img2mse, mse2psnr
+    from nerf_amd.datasets import pose_spherical
+    from oracle import nerf_oracle as O
+    e, _ = get_embedder(10, 0)
+    ed, _ = get_embedder(4, 0)
+    qf = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=e, embeddirs_fn=ed, netchunk=1 << 16)
+
+    def pair(seed_c, seed_f, gain):
+        out = []
+        for seed in (seed_c, seed_f):
+            sd = O.random_state_dict(seed)
+            sd["alpha_linear.weight"] *= gain
+            sd["alpha_linear.bias"] = sd["alpha_linear.bias"] * gain + 1.0
+            sd["rgb_linear.weight"] *= 8.0          # colours that vary over the scene
+            m = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+            m.load_state_dict(sd)
+            out.append(m.to(device))
+        return out
+    H = W = 48
+    K = _camera(H, W, 60.0)
+    common = dict(network_query_fn=qf, N_samples=32, N_importance=32, use_viewdirs=True, white_bkgd=True, ndc=False,
+                  near=2.0, far=6.0)
+    teacher = pair(101, 102, 6.0)
+    poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in (0.0, 70.0, 150.0, 230.0, 300.0)], 0).to(device)
+    with torch.no_grad():
+        images = torch.stack([render(H, W, K, chunk=1 << 15, c2w=p[:3, :4], network_fn=teacher[0], network_fine=teacher[1],
+                                     perturb=0.0, raw_noise_std=0.0, **common)[0] for p in poses], 0)
+    assert float(images.std()) > 0.02, "the teacher scene must not be flat"
+    student = pair(201, 202, 1.0)
+    params = list(student[0].parameters()) + list(student[1].parameters())
+    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    sampler = ViewSampler(images, poses, list(range(5)), H, W, K, 512, device=device, seed=3)
+    losses = []
+    for i in range(250):
+        rays, target = sampler.next(i)
+        rgb, _, _, ex = render(H, W, K, chunk=1 << 15, rays=rays, retraw=True, network_fn=student[0], network_fine=student[1],
+                               perturb=1.0, raw_noise_std=0.0, **common)
+        opt.zero_grad()
+        loss = img2mse(rgb, target) + img2mse(ex["rgb0"], target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    first, last = np.mean(losses[:10]), np.mean(losses[-10:])
+    assert np.isfinite(losses).all()
+    assert last < 0.25 * first, (first, last)
+    with torch.no_grad():
+        got = render(H, W, K, chunk=1 << 15, c2w=poses[1][:3, :4], network_fn=student[0], network_fine=student[1],
+                     perturb=0.0, raw_noise_std=0.0, **common)[0]
+    assert float(mse2psnr(img2mse(got, images[1]))) > 20.0
