@@ -6,6 +6,11 @@ fails loudly when it has not been built, and nothing here falls back to PyTorch 
 import ctypes
 import os
 
+# PyTorch first: it brings its own copy of the HIP runtime, and the library below must bind to that same copy (the
+# loader reuses an already loaded libamdhip64).  Loaded the other way round the process ends up with two runtimes,
+# and kernels launched through the second one find no device.
+import torch  # noqa: F401  isort: skip
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
 

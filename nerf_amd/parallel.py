@@ -13,6 +13,7 @@ Both work on any backend (the CPU tests use gloo).
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -35,6 +36,25 @@ def _world(group=None) -> Tuple[int, int]:
 def rank_world(group=None) -> Tuple[int, int]:
     """(rank, world size); (0, 1) when torch.distributed is not initialised."""
     return _world(group)
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int]:
+    """Join the process group that torch.distributed.run describes in the environment (one process per GPU): take the
+    device of LOCAL_RANK, initialise RCCL (backend "nccl"; NERF_DIST_BACKEND or `backend` overrides it, e.g. gloo to
+    rehearse several ranks on one GPU).  Does nothing in a single process or when a group already exists.
+    -> (rank, world size)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and dist.is_available() and not dist.is_initialized():
+        backend = backend or os.environ.get("NERF_DIST_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            index = local % torch.cuda.device_count()
+            torch.cuda.set_device(index)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", index))
+                return _world()
+        dist.init_process_group(backend)
+    return _world()
 
 
 def _host_staged(t: torch.Tensor, group) -> bool:
@@ -110,8 +130,13 @@ def render_path_sharded(render_poses, hwf, K, chunk: int, render_kwargs, render_
         block = torch.zeros((per, H, W, 4), dtype=dtype, device=dev)
         if mine:
             block[: len(mine)] = torch.stack(mine, 0)
-        out = torch.empty((world * per, H, W, 4), dtype=dtype, device=dev)
-        dist.all_gather_into_tensor(out, block, group=group)
+        if _host_staged(block, group):
+            pieces = [torch.empty(block.shape, dtype=dtype) for _ in range(world)]
+            dist.all_gather(pieces, block.cpu(), group=group)
+            out = torch.cat(pieces, 0).to(dev)
+        else:
+            out = torch.empty((world * per, H, W, 4), dtype=dtype, device=dev)
+            dist.all_gather_into_tensor(out, block, group=group)
         # frame i was rendered by rank i % world as its (i // world)-th
         order = torch.tensor([(i % world) * per + i // world for i in range(n)], device=dev)
         frames = out[order]
@@ -162,7 +187,12 @@ def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=Non
         return
     with torch.no_grad():
         flat = torch.cat([p.detach().reshape(-1) for p in params])
-        dist.broadcast(flat, src=src, group=group)
+        if _host_staged(flat, group):
+            host = flat.cpu()
+            dist.broadcast(host, src=src, group=group)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=src, group=group)
         off = 0
         for p in params:
             p.copy_(flat[off: off + p.numel()].view_as(p))

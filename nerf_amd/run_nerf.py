@@ -377,6 +377,21 @@ def _save_frames(prefix, frames8):
         _write_png(os.path.join(prefix, '{:03d}.png'.format(k)), fr)
 
 
+def _render_frames(rank, world, render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """render_path for the driver: alone, or with the frames dealt to all ranks (every rank must call it; rank 0
+    writes the PNGs).  -> (rgbs, disps) numpy arrays, complete on every rank."""
+    from . import parallel
+    if world == 1:
+        return render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=gt_imgs, savedir=savedir,
+                           render_factor=render_factor)
+    rgbs, disps = parallel.render_path_sharded(render_poses, hwf, K, chunk, render_kwargs, render_factor=render_factor)
+    rgbs, disps = rgbs.cpu().numpy(), disps.cpu().numpy()
+    if rank == 0 and savedir is not None:
+        for k, frame in enumerate(rgbs):
+            _write_png(os.path.join(savedir, '{:03d}.png'.format(k)), to8b(frame))  # noqa: F405
+    return rgbs, disps
+
+
 def load_dataset(args):
     """-> images, poses, render_poses, hwf, K, (i_train, i_val, i_test), near, far  (run_nerf.py:612-701)."""
     from . import datasets
@@ -426,8 +441,8 @@ def train(argv=None):
     from . import parallel
     from .raybatch import RayShuffler, ViewSampler
     args = config_parser().parse_args(argv)
+    rank, world = parallel.init_from_env()
     dev = ops.device()
-    rank, world = parallel.rank_world()
     images, poses, render_poses, hwf, K, (i_train, i_val, i_test), near, far = load_dataset(args)
     H, W, focal = hwf
     if args.render_test:
@@ -459,8 +474,8 @@ def train(argv=None):
             testsavedir = os.path.join(basedir, expname, 'renderonly_{}_{:06d}'.format('test' if args.render_test else 'path', start))
             os.makedirs(testsavedir, exist_ok=True)
             print('test poses shape', render_poses.shape)
-            rgbs, _ = render_path(render_poses, hwf, K, args.chunk, render_kwargs_test, gt_imgs=gt, savedir=testsavedir,
-                                  render_factor=args.render_factor)
+            rgbs, _ = _render_frames(rank, world, render_poses, hwf, K, args.chunk, render_kwargs_test, gt_imgs=gt,
+                                     savedir=testsavedir, render_factor=args.render_factor)
             print('Done rendering', testsavedir)
         return rgbs
 
@@ -502,27 +517,30 @@ def train(argv=None):
         for param_group in optimizer.param_groups:
             param_group['lr'] = new_lrate
 
-        if rank == 0:
-            if i % args.i_weights == 0:
-                path = os.path.join(basedir, expname, '{:06d}.tar'.format(i))
-                save_checkpoint(path, global_step, render_kwargs_train, optimizer)
-                print('Saved checkpoints at', path)
-            if i % args.i_video == 0 and i > 0:
-                with torch.no_grad():
-                    rgbs, disps = render_path(render_poses, hwf, K, args.chunk, render_kwargs_test)
+        if rank == 0 and i % args.i_weights == 0:
+            path = os.path.join(basedir, expname, '{:06d}.tar'.format(i))
+            save_checkpoint(path, global_step, render_kwargs_train, optimizer)
+            print('Saved checkpoints at', path)
+        # the periodic renders involve every rank (frames are dealt round-robin); rank 0 writes the files
+        if i % args.i_video == 0 and i > 0:
+            with torch.no_grad():
+                rgbs, disps = _render_frames(rank, world, render_poses, hwf, K, args.chunk, render_kwargs_test)
+            if rank == 0:
                 print('Done, saving', rgbs.shape, disps.shape)
                 moviebase = os.path.join(basedir, expname, '{}_spiral_{:06d}_'.format(expname, i))
                 _save_frames(moviebase + 'rgb', to8b(rgbs))  # noqa: F405
                 _save_frames(moviebase + 'disp', to8b(disps / np.max(disps)))  # noqa: F405
-            if i % args.i_testset == 0 and i > 0:
-                testsavedir = os.path.join(basedir, expname, 'testset_{:06d}'.format(i))
-                os.makedirs(testsavedir, exist_ok=True)
+        if i % args.i_testset == 0 and i > 0:
+            testsavedir = os.path.join(basedir, expname, 'testset_{:06d}'.format(i))
+            os.makedirs(testsavedir, exist_ok=True)
+            if rank == 0:
                 print('test poses shape', poses_dev[i_test].shape)
-                with torch.no_grad():
-                    render_path(poses_dev[i_test], hwf, K, args.chunk, render_kwargs_test, gt_imgs=images[i_test],
-                                savedir=testsavedir)
+            with torch.no_grad():
+                _render_frames(rank, world, poses_dev[i_test], hwf, K, args.chunk, render_kwargs_test, gt_imgs=images[i_test],
+                               savedir=testsavedir)
+            if rank == 0:
                 print('Saved test set')
-            if i % args.i_print == 0:
-                print(f"[TRAIN] Iter: {i} Loss: {loss.item()}  PSNR: {psnr.item()}")
+        if rank == 0 and i % args.i_print == 0:
+            print(f"[TRAIN] Iter: {i} Loss: {loss.item()}  PSNR: {psnr.item()}")
         global_step += 1
     return None if loss is None else float(loss.detach())

@@ -250,3 +250,24 @@ def test_optimisation_recovers_a_teacher_scene(device):
         got = render(H, W, K, chunk=1 << 15, c2w=poses[1][:3, :4], network_fn=student[0], network_fine=student[1],
                      perturb=0.0, raw_noise_std=0.0, **common)[0]
     assert float(mse2psnr(img2mse(got, images[1]))) > 20.0
+
+
+def test_command_line_entry_in_a_fresh_interpreter(device, tmp_path):
+    """`python -m nerf_amd --config ...` as users start it: a new interpreter, where the package (and with it the HIP
+    library) is imported before anything has touched the GPU."""
+    import subprocess
+    import sys
+    scene = os.path.join(tmp_path, "scene")
+    write_blender_scene(scene, n=(3, 1, 1), size=16)
+    cfg = os.path.join(tmp_path, "cli.txt")
+    with open(cfg, "w") as fh:
+        fh.write("expname = cli\nbasedir = %s\ndatadir = %s\ndataset_type = blender\nno_batching = True\nuse_viewdirs = True\n"
+                 "white_bkgd = True\nN_samples = 8\nN_importance = 8\nN_rand = 64\n" % (os.path.join(tmp_path, "logs"), scene))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, "-m", "nerf_amd", "--config", cfg, "--N_iters", "4", "--i_print", "1", "--i_weights", "3",
+                          "--i_testset", "1000", "--i_video", "1000", "--testskip", "1"], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert "[TRAIN] Iter: 3" in run.stdout
+    assert os.path.exists(os.path.join(tmp_path, "logs", "cli", "000003.tar"))
