@@ -76,18 +76,25 @@ def test_blender_reader_on_a_synthetic_scene(tmp_path):
     np.testing.assert_allclose(half[0, 0, 0], images[0, :2, :2].astype(np.float64).mean((0, 1)), rtol=1e-12)
 
 
-def test_llff_reader_on_a_synthetic_scene(tmp_path):
+def write_llff_scene(root, n=4, h=12, w=16, seed=5):
+    """poses_bounds.npy + images/ + images_2/ of a synthetic forward-facing capture."""
     from PIL import Image
-    D = _datasets()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     from gen_golden_datasets import synthetic_llff
-    poses, bds, _ = synthetic_llff(5, n=4, h=12, w=16)
-    arr = np.concatenate([poses.transpose(2, 0, 1).reshape(4, 15), bds.T], 1)
-    np.save(os.path.join(tmp_path, "poses_bounds.npy"), arr)
+    poses, bds, _ = synthetic_llff(seed, n=n, h=h, w=w)
+    arr = np.concatenate([poses.transpose(2, 0, 1).reshape(n, 15), bds.T], 1)
+    os.makedirs(root, exist_ok=True)
+    np.save(os.path.join(root, "poses_bounds.npy"), arr)
     rng = np.random.Generator(np.random.PCG64(9))
-    for sub, (h, w) in (("images", (12, 16)), ("images_2", (6, 8))):
-        os.makedirs(os.path.join(tmp_path, sub))
-        for k in range(4):
-            Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), "RGB").save(os.path.join(tmp_path, sub, f"{k:02d}.png"))
+    for sub, (hh, ww) in (("images", (h, w)), ("images_2", (h // 2, w // 2))):
+        os.makedirs(os.path.join(root, sub))
+        for k in range(n):
+            Image.fromarray(rng.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8), "RGB").save(os.path.join(root, sub, f"{k:02d}.png"))
+
+
+def test_llff_reader_on_a_synthetic_scene(tmp_path):
+    D = _datasets()
+    write_llff_scene(str(tmp_path))
     images, p, b, render_poses, i_test = D.load_llff_data(str(tmp_path), factor=2)
     assert images.shape == (4, 6, 8, 3) and p.shape == (4, 3, 5) and b.shape == (4, 2) and render_poses.shape == (120, 3, 5)
     assert p[0, 0, 4] == 6 and p[0, 1, 4] == 8 and abs(p[0, 2, 4] - 11.5 / 2) < 1e-6      # hwf follows the shrunk images

@@ -271,3 +271,33 @@ def test_command_line_entry_in_a_fresh_interpreter(device, tmp_path):
     assert run.returncode == 0, run.stderr[-2000:]
     assert "[TRAIN] Iter: 3" in run.stdout
     assert os.path.exists(os.path.join(tmp_path, "logs", "cli", "000003.tar"))
+
+
+def test_train_driver_on_a_forward_facing_scene(device, tmp_path, capsys):
+    """The LLFF branch of the driver (configs/fern.txt: NDC rays, near 0 / far 1, density noise, every llffhold-th view held
+    out, batching over all rays) on a synthetic capture: trains, checkpoints, renders the held-out views and the spiral."""
+    from nerf_amd.run_nerf import train
+    from test_datasets import write_llff_scene
+    scene = os.path.join(tmp_path, "capture")
+    write_llff_scene(scene, n=6, h=12, w=16)
+    cfg = os.path.join(tmp_path, "ff.txt")
+    with open(cfg, "w") as fh:
+        fh.write("expname = ff\nbasedir = %s\ndatadir = %s\ndataset_type = llff\nfactor = 2\nllffhold = 3\nN_rand = 32\n"
+                 "N_samples = 8\nN_importance = 8\nuse_viewdirs = True\nraw_noise_std = 1e0\n" % (os.path.join(tmp_path, "logs"), scene))
+    common = ["--config", cfg, "--i_print", "1", "--i_weights", "3", "--i_testset", "3", "--i_video", "1000"]
+    loss = train(common + ["--N_iters", "4"])
+    assert np.isfinite(loss)
+    out = capsys.readouterr().out
+    assert "NEAR FAR 0.0 1.0" in out or "[TRAIN] Iter: 3" in out
+    log = os.path.join(tmp_path, "logs", "ff")
+    assert os.path.exists(os.path.join(log, "000003.tar"))
+    assert sorted(os.listdir(os.path.join(log, "testset_000003"))) == ["000.png", "001.png"]     # views 0 and 3 of six
+    rgbs = train(common + ["--render_only", "--render_factor", "2"])
+    assert rgbs.shape == (120, 3, 4, 3) and np.isfinite(rgbs).all()
+    # inward-facing capture flags (run_nerf.py:563-572): spherified poses, no NDC, samples linear in disparity
+    cfg2 = os.path.join(tmp_path, "ff360.txt")
+    with open(cfg2, "w") as fh:
+        fh.write(open(cfg).read().replace("expname = ff", "expname = ff360") + "no_ndc = True\nspherify = True\nlindisp = True\n")
+    assert np.isfinite(train(["--config", cfg2, "--N_iters", "3", "--i_print", "1", "--i_weights", "1000", "--i_testset", "1000",
+                              "--i_video", "1000"]))
+    assert "[TRAIN] Iter: 2" in capsys.readouterr().out
