@@ -305,7 +305,7 @@ def main():
     pts = sum(n for n, _ in mlp)
     secs = sum(t for _, t in mlp)
     achieved = pts * FLOP_PER_POINT_FWD / secs / 1e12 if secs > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd<viewdirs, inference> (fp32 MFMA 32x32x2)", "achieved": round(achieved, 2),
+    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd_x4<viewdirs> (fp32 MFMA 16x16x4, 16 points per wave, two waves per SIMD)", "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                 "traffic": round(PMC_HBM_BYTES_PER_POINT * pts / max(1, len(mlp))),
                 "traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of a separate rocprofv3 run, see profiles/",

@@ -19,10 +19,12 @@
 // fp32 path the raw outputs differ by about 1e-2 of their scale (tolerance stated in the tests).
 #include "common.hpp"
 #include "mlp_core.hpp"
+#include "mlp_tile16.hpp"
 
 using namespace nerfhip;
 using namespace nerflayout;
 using namespace nerfmlp;
+using namespace nerftile16;
 
 namespace {
 
@@ -51,33 +53,6 @@ __host__ __device__ inline int bf16_stream_slabs(int use_viewdirs) { return (bf1
 // feature (inside a 32-feature k-step) that k-slot j of lane group g stands for
 __host__ __device__ inline int kslot_feature(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); }
 
-// Encoded position: 64 slots per point = 2 k-steps x 4 groups x 8; group g evaluates the (frequency, axis) pairs
-// c0(g) .. c0(g)+np(g)-1 (8, 8, 7, 7 of the 30) and keeps sin and cos side by side; the raw coordinates fill
-// the last slots of groups 2 and 3.  -> encoded feature index (run_nerf_helpers.py:13-66 order), or -1 (padding).
-__host__ __device__ inline int enc16_first_pair(int g) { return g < 2 ? 8 * g : 16 + 7 * (g - 2); }
-__host__ __device__ inline int enc16_pts_feature(int ks, int g, int j) {
-    const int q = 8 * ks + j, i = q >> 1, np = g < 2 ? 8 : 7;
-    if (i < np) {
-        const int c = enc16_first_pair(g) + i, k = c / 3, d = c % 3;
-        return 3 + 6 * k + 3 * (q & 1) + d;
-    }
-    if (g == 2) return q - 14;            // x, y
-    return q == 14 ? 2 : -1;              // z, padding
-}
-// Encoded direction: 32 slots = 4 groups x 8; group g evaluates pairs 3g .. 3g+2, raw components in slots 6, 7.
-__host__ __device__ inline int enc16_dirs_feature(int g, int j) {
-    if (j < 6) {
-        const int c = 3 * g + (j >> 1), k = c / 3, d = c % 3;
-        return 3 + 6 * k + 3 * (j & 1) + d;
-    }
-    if (g == 0) return j - 6;             // x, y
-    return (g == 1 && j == 6) ? 2 : -1;   // z
-}
-
-// aux tables behind the stream (floats, natural feature order), copied to LDS once per workgroup:
-//   bias[10][256] (layers 0..7, feature, views (128 used)); view branch: alpha[256], rgb[3][128], alpha_b, rgb_b[3];
-//   otherwise output_linear[8][256], out_b[8]
-constexpr int AUX16_BIAS = 0, AUX16_HEAD = 10 * 256, AUX16_FLOATS = AUX16_HEAD + 8 * 256 + 8;
 __host__ __device__ inline int64_t bf16_packed_bytes(int use_viewdirs) {
     return (int64_t)bf16_stream_slabs(use_viewdirs) * SLAB16_BYTES + (int64_t)AUX16_FLOATS * 4;
 }
@@ -109,29 +84,6 @@ __host__ __device__ inline int64_t bf16_stream_source(int use_viewdirs, int outp
     if (ks < 8) return po.views_w + (int64_t)row * po.views_in + 32 * ks + kslot_feature(g, j);
     const int f = enc16_dirs_feature(g, j);
     return f < 0 ? -1 : po.views_w + (int64_t)row * po.views_in + W + f;
-}
-
-__host__ __device__ inline int64_t bf16_aux_source(int use_viewdirs, int output_ch, int a) {
-    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
-    if (a < AUX16_HEAD) {
-        const int layer = a >> 8, f = a & 255;
-        if (layer < 8) return po.pts_b[layer] + f;
-        if (!use_viewdirs) return -1;
-        if (layer == 8) return po.feat_b + f;
-        return f < W / 2 ? po.views_b + f : -1;
-    }
-    a -= AUX16_HEAD;
-    if (use_viewdirs) {
-        if (a < 256) return po.alpha_w + a;
-        a -= 256;
-        if (a < 384) return po.rgb_w + a;
-        a -= 384;
-        if (a == 0) return po.alpha_b;
-        return a < 4 ? po.rgb_b + (a - 1) : -1;
-    }
-    if (a < 8 * 256) return (a >> 8) < output_ch ? po.out_w + a : -1;
-    a -= 8 * 256;
-    return a < output_ch ? po.out_b + a : -1;
 }
 
 // ---- the slab ring as one wave sees it ----------------------------------------------------------
@@ -387,7 +339,7 @@ __global__ void __launch_bounds__(256) k_pack_bf16(int use_viewdirs, int output_
             const __bf16 r = (__bf16)(src < 0 ? 0.0f : params[src]);
             s16[i] = __builtin_bit_cast(unsigned short, r);
         } else {
-            const int64_t src = bf16_aux_source(use_viewdirs, output_ch, (int)(i - padded));
+            const int64_t src = aux16_source(use_viewdirs, output_ch, (int)(i - padded));
             aux[i - padded] = src < 0 ? 0.0f : params[src];
         }
     }

@@ -94,6 +94,7 @@ class NeRF(nn.Module):
         self._pack = None
         self._pack_table = None
         self._pack16 = None
+        self._packx4 = None
         # 'f32' (default; fp32 MFMA, the reference's precision) or 'bf16' (no-grad queries only: bf16 operands,
         # fp32 accumulation, raw outputs within ~1e-2 of their scale; training always runs fp32)
         self.mlp_dtype = 'f32'
@@ -127,6 +128,7 @@ class NeRF(nn.Module):
                 fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd, self._pack_table)
             self._pack, self._pack_key = (fwd, bwd, flat), key
             self._pack16 = None
+            self._packx4 = None
         return self._pack
 
     def _packed_bf16(self):
@@ -134,6 +136,12 @@ class NeRF(nn.Module):
         if self._pack16 is None:
             self._pack16 = ops.pack_weights_bf16(flat, self.use_viewdirs, self.output_ch)
         return self._pack16
+
+    def _packed_x4(self):
+        flat = self._packed(False)[2]
+        if self._packx4 is None:
+            self._packx4 = ops.pack_weights_x4(flat, self.use_viewdirs, self.output_ch)
+        return self._packx4
 
     def _split_flat(self, flat: torch.Tensor):
         out, off = [], 0

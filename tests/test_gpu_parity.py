@@ -325,6 +325,18 @@ def test_mlp_forward_ragged_sizes_and_peaky_weights(device):
             want = O.query_field(pts, vd, sd)
         scale = float(want.abs().max())
         close(raw, want, 3e-5, 3e-6 * max(1.0, scale), f"mlp {n}x{s}")
+        # the three fp32 routes to the same numbers: 16-point tiles (what no_grad queries run, checked above), the
+        # 32-point-tile entry without saving, and the training forward that saves activations
+        from nerf_amd import ops
+        flat_pts, dirs = pts.reshape(-1, 3).to(device), vd.to(device)
+        with torch.no_grad():
+            raw32 = ops.mlp_forward(flat_pts, dirs, m._packed(False)[0], True, 5, s)
+            raw16 = ops.mlp_forward_x4(flat_pts, dirs, m._packed_x4(), True, 5, s)
+        close(raw32.reshape(n, s, 4), want, 3e-5, 3e-6 * max(1.0, scale), f"mlp 32-point tiles {n}x{s}")
+        close(raw16.reshape(n, s, 4), raw, 0, 0, f"mlp 16-point tiles {n}x{s} (same kernel as the query)")
+        raw_train = qf(pts.to(device), vd.to(device), m)
+        assert raw_train.requires_grad
+        close(raw_train, want, 3e-5, 3e-6 * max(1.0, scale), f"mlp training forward {n}x{s}")
 
 
 def _rng_inputs(n, sc, si, perturb, std):
