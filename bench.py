@@ -35,9 +35,9 @@ FLOP_PER_POINT_FWD = 1186816          # 2 * 593,408 MAC: one NeRF.forward on one
 FLOP_PER_POINT_TRAIN = 3489024        # forward + dW + dX
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X v_mfma_f32_32x32x2_f32 peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 # HBM bytes per point of the inference kernel from rocprofv3 PMC passes (profiles/r1_pmc_mlp_fwd.txt):
-# (2 x FETCH_SIZE + WRITE_SIZE) / points = (2 x 36,549 KiB + 64,000 KiB) / 4,096,000 points per launch.
+# (2 x FETCH_SIZE + WRITE_SIZE) / points = (2 x 36,774 KiB + 64,000 KiB) / 4,096,000 points per launch.
 # The algorithmic figure is 28 B/point (12 B position in, 16 B raw out) + 12 B per ray of view direction.
-PMC_HBM_BYTES_PER_POINT = 34.27
+PMC_HBM_BYTES_PER_POINT = 34.39
 
 
 def lego_camera(H, W):
