@@ -155,12 +155,13 @@ int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int ou
 
 /* Inference form of nerf_mlp_fwd on 16-point tiles (v_mfma_f32_16x16x4_f32, two waves per SIMD): the same fp32
  * arithmetic for NeRF.forward under no_grad (run_nerf_helpers.py:109-133 behind run_nerf.py:40-66), same arguments
- * and outputs, no activation saving.  packed_x4: nerf_mlp_packed_x4_floats() floats built by nerf_pack_weights_x4
+ * and outputs, `act` as in nerf_mlp_fwd (NULL for inference; otherwise the saved activations and ReLU mask words in
+ * the layout nerf_mlp_bwd reads).  packed_x4: nerf_mlp_packed_x4_floats() floats built by nerf_pack_weights_x4
  * from the flat parameter vector (the module's parameters concatenated in state_dict order). */
 int64_t nerf_mlp_packed_x4_floats(int use_viewdirs);
 int nerf_pack_weights_x4(int use_viewdirs, int output_ch, const float* params, float* packed_x4, void* stream);
 int nerf_mlp_fwd_x4(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
-                    int use_viewdirs, int output_ch, const float* packed_x4, float* out, void* stream);
+                    int use_viewdirs, int output_ch, const float* packed_x4, float* out, float* act, void* stream);
 
 /* bf16-operand / fp32-accumulate inference variant of nerf_mlp_fwd (same arguments and outputs).
  * packed_bf16: nerf_mlp_packed_bf16_bytes() bytes built by nerf_pack_weights_bf16 from the flat

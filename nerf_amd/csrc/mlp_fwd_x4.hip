@@ -116,9 +116,14 @@ __device__ __forceinline__ void need_now(const f32x4& a, const f32x4& b) { asm v
 // in(kb, j) = this lane's value of input feature 16 kb + 4 g + j for its point (a register of the input array, or of
 // the encodings).  A step = the two blocks (row tiles 2u, 2u+1) of one k-block = eight MFMAs that alternate between
 // the two accumulators; the blocks of step s+DEPTH are read from LDS before the MFMAs of step s issue.
-template <int NOUT, int NKB, bool RELU, typename In>
+// SAVE (training): a finished tile pair is also stored for the backward pass, one 16-byte store per tile and lane
+// into the blocked layout (`srows` = the layer's first row group + this lane's offset g * GROUP_FLOATS + 4 * (point in
+// tile): a lane's four registers of tile t are the four rows of row group 4 t + g); with MASK its ReLU mask bits are
+// collected in `mb`, dword t / 4, bit 8 (t % 4) + i for register i of tile t (the lane's share of the layout the
+// backward-data kernel reads; see save_mask()).
+template <int NOUT, int NKB, bool RELU, bool SAVE, bool MASK, typename In>
 __device__ __forceinline__ void layer_x4(StreamX4& st, int lane, const float*& cur, In in, f32x4 (&out)[16],
-                                         const float* bias_g) {
+                                         const float* bias_g, float* srows, uint32_t (&mb)[4]) {
     constexpr int NS = (NOUT / 2) * NKB;
     static_assert(NOUT % 2 == 0 && NKB >= 3, "row tiles come in pairs; the epilogue needs three steps of cover");
     f32x4 abuf[3][2];
@@ -127,13 +132,23 @@ __device__ __forceinline__ void layer_x4(StreamX4& st, int lane, const float*& c
         out[2 * U + 1] = *reinterpret_cast<const f32x4*>(bias_g + 32 * U + 16);
     };
     auto relu_pair = [&]<int U>() {
-        if constexpr (RELU) {
+        static_for<2>([&]<int TT>() {
+            constexpr int t = 2 * U + TT;
+            if constexpr (RELU) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) out[2 * U + t][i] = fmaxf(out[2 * U + t][i], 0.0f);
-        }
+                for (int i = 0; i < 4; ++i) {
+                    const float y = fmaxf(out[t][i], 0.0f);
+                    out[t][i] = y;
+                    if constexpr (MASK) {   // y >= 0, so "positive" = "bits != 0"
+                        const uint32_t one = __float_as_uint(y) < 1u ? __float_as_uint(y) : 1u;
+                        mb[t >> 2] |= one << (8 * (t & 3) + i);
+                    }
+                }
+            }
+            if constexpr (SAVE) *reinterpret_cast<f32x4*>(srows + 4 * t * GROUP_FLOATS) = out[t];
+        });
     };
+    if constexpr (MASK) mb[0] = mb[1] = mb[2] = mb[3] = 0u;
     // The blocks of step s+2 are requested at the END of step s, after the wait for those of step s+1: that wait is
     // the only one in the loop and finds reads that were issued a whole step (eight MFMAs) earlier.  Left to itself the
     // compiler waits right before a step's first MFMA with lgkmcnt(0), i.e. also for the reads it issued one MFMA ago.
@@ -183,10 +198,10 @@ __device__ __forceinline__ float head_x4(const f32x4 (&A)[16], const float* w_g)
     return s + __shfl_xor(s, 32, 64);
 }
 
-template <bool VIEWDIRS>
+template <bool VIEWDIRS, bool SAVE>
 __global__ void __launch_bounds__(X4_THREADS, 2)
 k_mlp_fwd_x4(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
-             int output_ch, const float* __restrict__ packed, float* __restrict__ out) {
+             int output_ch, const float* __restrict__ packed, float* __restrict__ out, float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) float smem_x4[];
     float* ring = smem_x4;
     float* aux = smem_x4 + X4_RING_FLOATS;
@@ -247,19 +262,67 @@ k_mlp_fwd_x4(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, cons
     auto inPE = [&]<int kb, int j>() -> float { if constexpr (kb < 16) return P[kb][j]; else return E[4 * (kb - 16) + j]; };
     auto inPD = [&]<int kb, int j>() -> float { if constexpr (kb < 16) return P[kb][j]; else return D[4 * (kb - 16) + j]; };
 
-    layer_x4<16, 4, true>(st, lane, cur, inE, P, bias);                 // L0: encoded position -> P
-    layer_x4<16, 16, true>(st, lane, cur, inP, Q, bias + 1 * 256);      // L1
-    layer_x4<16, 16, true>(st, lane, cur, inQ, P, bias + 2 * 256);      // L2
-    layer_x4<16, 16, true>(st, lane, cur, inP, Q, bias + 3 * 256);      // L3
-    layer_x4<16, 16, true>(st, lane, cur, inQ, P, bias + 4 * 256);      // L4
-    layer_x4<16, 20, true>(st, lane, cur, inPE, Q, bias + 5 * 256);     // L5: hidden ++ encoded position (skip)
-    layer_x4<16, 16, true>(st, lane, cur, inQ, P, bias + 6 * 256);      // L6
-    layer_x4<16, 16, true>(st, lane, cur, inP, Q, bias + 7 * 256);      // L7 -> Q
+    // ---- training: this workgroup's tile of the saved activations (mlp_layout.hpp), this lane's point inside it
+    const int pw = wave * 16 + (lane & 15);
+    float* const tile = SAVE ? act + (int64_t)blockIdx.x * act_rows(UV) * TILE_PTS : nullptr;
+    float* const lane_rows = SAVE ? tile + g * GROUP_FLOATS + pw * 4 : nullptr;
+    auto rows = [&](int row) { return lane_rows + (row / 4) * GROUP_FLOATS; };
+    uint32_t mb[4] = {0u, 0u, 0u, 0u};
+    // The backward-data kernel works on 32-point tiles: its lane (point, half h) reads one 16-byte word per masked layer
+    // whose dword d, bit 16 (T % 2) + r stands for register r of its tile T = 2 d + ..., i.e. for feature row
+    // 32 T + (r & 3) + 8 (r >> 2) + 4 h.  Lanes (point, g = h) and (point, g = h + 2) of this kernel hold those rows
+    // between them, in nibbles that alternate: bit 8 (t % 4) + 4 (g >> 1) + i of dword t / 4.
+    auto save_mask = [&](int m) {
+        if constexpr (SAVE) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t mine = mb[d] << (4 * (g >> 1));
+                w[d] = mine | (uint32_t)__shfl_xor((int)mine, 32, 64);
+            }
+            if (g < 2) *reinterpret_cast<u32x4*>(tile + act_mask_offset(UV, m, pw >> 5, g * 32 + (pw & 31))) = w;
+        }
+    };
+    if constexpr (SAVE) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int f = enc16_pts_feature(q >> 3, g, q & 7), row = ACT_ENC_PTS + (f < 0 ? 63 : f);
+            tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid && f >= 0) ? E[q] : 0.0f;
+        }
+        if (VIEWDIRS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int f = enc16_dirs_feature(g, q);
+                // the five slots without a feature zero the padding rows 27..31
+                const int row = ACT_ENC_DIRS + (f >= 0 ? f : 27 + (g == 1 ? 0 : 2 * (g - 2) + 1 + (q - 6)));
+                tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid && f >= 0) ? D[q] : 0.0f;
+            }
+        }
+    }
+
+    layer_x4<16, 4, true, SAVE, SAVE>(st, lane, cur, inE, P, bias, rows(ACT_H0), mb);                     // L0: encoded position -> P
+    save_mask(0);
+    layer_x4<16, 16, true, SAVE, SAVE>(st, lane, cur, inP, Q, bias + 1 * 256, rows(ACT_H0 + 1 * 256), mb); // L1
+    save_mask(1);
+    layer_x4<16, 16, true, SAVE, SAVE>(st, lane, cur, inQ, P, bias + 2 * 256, rows(ACT_H0 + 2 * 256), mb); // L2
+    save_mask(2);
+    layer_x4<16, 16, true, SAVE, SAVE>(st, lane, cur, inP, Q, bias + 3 * 256, rows(ACT_H0 + 3 * 256), mb); // L3
+    save_mask(3);
+    layer_x4<16, 16, true, SAVE, SAVE>(st, lane, cur, inQ, P, bias + 4 * 256, rows(ACT_H0 + 4 * 256), mb); // L4
+    save_mask(4);
+    layer_x4<16, 20, true, SAVE, SAVE>(st, lane, cur, inPE, Q, bias + 5 * 256, rows(ACT_H0 + 5 * 256), mb); // L5: hidden ++ encoded position (skip)
+    save_mask(5);
+    layer_x4<16, 16, true, SAVE, SAVE>(st, lane, cur, inQ, P, bias + 6 * 256, rows(ACT_H0 + 6 * 256), mb); // L6
+    save_mask(6);
+    layer_x4<16, 16, true, SAVE, SAVE>(st, lane, cur, inP, Q, bias + 7 * 256, rows(ACT_H0 + 7 * 256), mb); // L7 -> Q
+    save_mask(7);
     if constexpr (VIEWDIRS) {
         const float* hb = hw + 256 + 384;
         const float sigma = head_x4<16>(Q, hw + 4 * g) + hb[0];
-        layer_x4<16, 16, false>(st, lane, cur, inQ, P, bias + 8 * 256);  // feature_linear (no activation) -> P
-        layer_x4<8, 18, true>(st, lane, cur, inPD, Q, bias + 9 * 256);   // views layer: feature ++ encoded direction -> Q[0..7]
+        layer_x4<16, 16, false, SAVE, false>(st, lane, cur, inQ, P, bias + 8 * 256, rows(ACT_FEAT), mb);  // feature_linear (no activation) -> P
+        layer_x4<8, 18, true, SAVE, SAVE>(st, lane, cur, inPD, Q, bias + 9 * 256, rows(ACT_VIEWS), mb);   // views layer: feature ++ encoded direction -> Q[0..7]
+        save_mask(8);
         const float r = head_x4<8>(Q, hw + 256 + 4 * g) + hb[1];
         const float gg = head_x4<8>(Q, hw + 256 + 128 + 4 * g) + hb[2];
         const float b = head_x4<8>(Q, hw + 256 + 256 + 4 * g) + hb[3];
@@ -303,7 +366,7 @@ int nerf_pack_weights_x4(int use_viewdirs, int output_ch, const float* params, f
 }
 
 int nerf_mlp_fwd_x4(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
-                    int output_ch, const float* packed_x4, float* out, void* stream) {
+                    int output_ch, const float* packed_x4, float* out, float* act, void* stream) {
     NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd_x4: n_pts=%lld", (long long)n_pts);
     if (n_pts == 0) return 0;
     NERF_REQUIRE(pts && packed_x4 && out, "nerf_mlp_fwd_x4: null pointer");
@@ -318,11 +381,12 @@ int nerf_mlp_fwd_x4(int64_t n_pts, int pts_per_ray, const float* pts, const floa
                                            (int)X4_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_x4: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X4_THREADS), X4_LDS_BYTES, as_stream(stream), n_pts, ppr, pts, vd,
-                           och, packed_x4, out);
+                           och, packed_x4, out, act);
         return launched("nerf_mlp_fwd_x4");
     };
-    if (use_viewdirs) return go(k_mlp_fwd_x4<true>, pts_per_ray, viewdirs, 4);
-    return go(k_mlp_fwd_x4<false>, 1, nullptr, output_ch);
+    NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd_x4: act must be 16-byte aligned");
+    if (use_viewdirs) return act ? go(k_mlp_fwd_x4<true, true>, pts_per_ray, viewdirs, 4) : go(k_mlp_fwd_x4<true, false>, pts_per_ray, viewdirs, 4);
+    return act ? go(k_mlp_fwd_x4<false, true>, 1, nullptr, output_ch) : go(k_mlp_fwd_x4<false, false>, 1, nullptr, output_ch);
 }
 
 }  // extern "C"

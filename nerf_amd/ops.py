@@ -348,17 +348,17 @@ def pack_weights_x4(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> t
 
 
 def mlp_forward_x4(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_x4: torch.Tensor, use_viewdirs: bool,
-                   output_ch: int, pts_per_ray: int) -> torch.Tensor:
-    """fp32 inference on raw positions [P,3] (+ per-ray viewdirs): the 16-point-tile kernel."""
+                   output_ch: int, pts_per_ray: int, act: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 forward on raw positions [P,3] (+ per-ray viewdirs): the 16-point-tile kernel; `act` as in mlp_forward."""
     pts = _f32c(pts, "pts")
     n_pts = pts.numel() // 3
     out = torch.empty((n_pts, 4 if use_viewdirs else output_ch), dtype=torch.float32, device=pts.device)
     if use_viewdirs:
         viewdirs = _f32c(viewdirs, "viewdirs")
         assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
-    with torch.cuda.device(pts.device), _timed("mlp_fwd", n_pts):
+    with torch.cuda.device(pts.device), _timed("mlp_fwd" if act is None else "mlp_fwd_save", n_pts):
         check(lib.nerf_mlp_fwd_x4(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
-                                  int(use_viewdirs), output_ch, packed_x4.data_ptr(), out.data_ptr(), _stream()))
+                                  int(use_viewdirs), output_ch, packed_x4.data_ptr(), out.data_ptr(), _ptr(act), _stream()))
     return out
 
 
@@ -410,7 +410,10 @@ class _FusedMLP(torch.autograd.Function):
         fwd, bwd, flat = model._packed(need_grad)
         n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
-        out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
+        if pts_per_ray > 0:   # raw positions: the 16-point-tile kernel (the 32-point one serves pre-encoded inputs)
+            out = mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
+        else:
+            out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
         if need_grad:
             ctx.save_for_backward(act, fwd, bwd, flat)
             ctx.model = model

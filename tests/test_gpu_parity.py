@@ -473,6 +473,30 @@ def test_mlp_backward_matches_reference_and_oracle(device):
         np.testing.assert_allclose(sums[1], g[f"vd_gsum.{k}"][1], rtol=1e-4)
 
 
+def _relu_margin(sd, pts, vd, use_vd):
+    """Per point, the smallest |pre-activation| over every ReLU unit of the network, from an fp64 evaluation.  A unit
+    within fp32 rounding of zero may land on either side in any fp32 evaluation (this kernel, another tiling of it, the
+    CPU), which moves the gradients by that point's whole contribution: strict gradient comparisons leave such points
+    out by giving them a zero upstream gradient."""
+    F = torch.nn.functional
+    sd = {k: v.double() for k, v in sd.items()}
+    flat = pts.double().reshape(-1, 3)
+    x = O.encode(flat, 10)
+    h, margin = x, torch.full((flat.shape[0],), float("inf"), dtype=torch.float64)
+    for i in range(8):
+        z = F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"])
+        margin = torch.minimum(margin, z.abs().amin(-1))
+        h = torch.relu(z)
+        if i == 4:
+            h = torch.cat([x, h], -1)
+    if use_vd:
+        dirs = O.encode(vd.double()[:, None].expand(pts.shape).reshape(-1, 3), 4)
+        feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+        z = F.linear(torch.cat([feat, dirs], -1), sd["views_linears.0.weight"], sd["views_linears.0.bias"])
+        margin = torch.minimum(margin, z.abs().amin(-1))
+    return margin.reshape(pts.shape[:-1])
+
+
 def test_mlp_backward_sizes_and_no_view_branch(device):
     """Ragged point counts (tile padding, empty K slices) and the output_linear head, against oracle autograd."""
     rng = np.random.Generator(np.random.PCG64(10))
@@ -493,6 +517,7 @@ def test_mlp_backward_sizes_and_no_view_branch(device):
         vd = vd / vd.norm(dim=-1, keepdim=True)
         raw = qf(pts.to(device), vd.to(device) if use_vd else None, m)
         G = T(rng.normal(size=tuple(raw.shape)).astype(np.float32))
+        G = G * (_relu_margin(sd, pts, vd, use_vd) > 1e-5)[..., None].float()     # (a handful of points per million units)
         (raw * G.to(device)).sum().backward()
         # truth in fp64: with thousands of points the fp32 CPU reduction is itself ~1e-4 of the scale off
         params = {k: v.double().requires_grad_(True) for k, v in sd.items()}
@@ -828,7 +853,8 @@ def test_render_option_paths(device):
         if par[k].grad is None:       # views_linears exists in the module but takes no part without view directions
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        _grad_close(p.grad, par[k].grad, "no-viewdirs grad " + k, rtol=2e-3, atol_frac=1e-4)
+        # (against an fp32 CPU evaluation, itself ~1e-4 of the scale away from the fp64 value on sums over 16,000 points)
+        _grad_close(p.grad, par[k].grad, "no-viewdirs grad " + k, rtol=2e-3, atol_frac=4e-4)
     assert float(mn.output_linear.weight.grad[4].abs().max()) == 0.0
 
     # identity encoding: the network sees raw xyz and raw directions
