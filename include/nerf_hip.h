@@ -139,6 +139,12 @@ int nerf_pack_table(int use_viewdirs, int output_ch, int32_t* table, void* strea
 int nerf_pack_weights_table(int use_viewdirs, const int32_t* table, const float* params, float* packed_fwd,
                             float* packed_bwd, void* stream);
 
+/* out[i] = table[i] < 0 ? 0 : params[table[i]] for i < n (all DEVICE): any packed stream as a gather through a map
+ * the caller keeps (e.g. obtained once by packing the vector 1, 2, 3, ... and subtracting one).  Part of the weight
+ * hand-over of NeRF.forward (run_nerf_helpers.py:109-133); upstream has no counterpart, its GEMMs read the module's
+ * tensors directly. */
+int nerf_gather(const int32_t* table, const float* params, float* out, int64_t n, void* stream);
+
 /* NeRF.forward on encoded points (run_nerf_helpers.py:109-133 after run_nerf.py:46-58).
  * pts [n_pts,3]; viewdirs [n_rays,3] (ray of point p = p / pts_per_ray) or NULL when the network
  * has no view branch; out [n_pts, out_ch] (out_ch = 4 with view directions, else output_ch).
@@ -180,6 +186,15 @@ int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const fl
 int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float* act,
                  int use_viewdirs, int output_ch, const float* packed_fwd, const float* packed_bwd,
                  float* scratch, float* d_params, void* stream);
+
+/* nerf_mlp_bwd with its first stage (the gradients of every layer's pre-activations) on 16-point tiles, two waves
+ * per SIMD: the mirror of nerf_mlp_fwd_x4, for the same autograd-derived backward of run_nerf_helpers.py:109-133.
+ * Same d_out / act / scratch / d_params as nerf_mlp_bwd (act from either forward).  packed_x4: the stream of
+ * nerf_pack_weights_x4; packed_bwd_x4: nerf_mlp_packed_bwd_x4_floats() floats built by nerf_pack_weights_bwd_x4. */
+int64_t nerf_mlp_packed_bwd_x4_floats(int use_viewdirs);
+int nerf_pack_weights_bwd_x4(int use_viewdirs, int output_ch, const float* params, float* packed_bwd_x4, void* stream);
+int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                    const float* packed_x4, const float* packed_bwd_x4, float* scratch, float* d_params, void* stream);
 
 #ifdef __cplusplus
 }

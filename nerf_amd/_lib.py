@@ -53,9 +53,13 @@ SIGNATURES = {
     "nerf_pack_weights_table": (_i, [_i, _p, _p, _p, _p, _p]),
     "nerf_mlp_fwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_mlp_fwd_encoded": (_i, [_l, _p, _i, _i, _p, _p, _p, _p]),
+    "nerf_gather": (_i, [_p, _p, _p, _l, _p]),
     "nerf_mlp_packed_x4_floats": (_l, [_i]),
     "nerf_pack_weights_x4": (_i, [_i, _i, _p, _p, _p]),
     "nerf_mlp_fwd_x4": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "nerf_mlp_packed_bwd_x4_floats": (_l, [_i]),
+    "nerf_pack_weights_bwd_x4": (_i, [_i, _i, _p, _p, _p]),
+    "nerf_mlp_bwd_x4": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "nerf_mlp_packed_bf16_bytes": (_l, [_i]),
     "nerf_pack_weights_bf16": (_i, [_i, _i, _p, _p, _p]),
     "nerf_mlp_fwd_bf16": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p]),

@@ -17,6 +17,7 @@
 //     atomics).
 #include "common.hpp"
 #include "mlp_core.hpp"
+#include "mlp_x4.hpp"
 
 using namespace nerfhip;
 using namespace nerflayout;
@@ -474,49 +475,12 @@ void assign_splits(DwTasks& tk, const int* cost, int64_t nchunks, int n_wg) {
 
 }  // namespace
 
-extern "C" {
-
-int64_t nerf_mlp_scratch_floats(int use_viewdirs, int64_t n_pts) { return scratch_floats(use_viewdirs, 8, n_pts); }
-
-int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float* act, int use_viewdirs, int output_ch,
-                 const float* packed_fwd, const float* packed_bwd, float* scratch, float* d_params, void* stream_) {
-    (void)pts_per_ray;
-    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd: n_pts=%lld", (long long)n_pts);
-    NERF_REQUIRE(d_params, "nerf_mlp_bwd: null d_params");
-    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd: output_ch=%d not in 1..8", output_ch);
-    hipStream_t stream = as_stream(stream_);
-    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
-    if (n_pts == 0) {
-        hipError_t e = hipMemsetAsync(d_params, 0, po.total * sizeof(float), stream);
-        return e == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
-    }
-    NERF_REQUIRE(d_out && act && packed_fwd && packed_bwd && scratch, "nerf_mlp_bwd: null pointer");
-    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch) |
-                   reinterpret_cast<uintptr_t>(packed_fwd) | reinterpret_cast<uintptr_t>(packed_bwd)) & 15) == 0,
-                 "nerf_mlp_bwd: buffers must be 16-byte aligned");
-    const int64_t ldp = padded_points(n_pts);
-    const int64_t blocks = ldp / TILE_PTS;
-    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_bwd: n_pts=%lld too large for one call", (long long)n_pts);
-    const int64_t slab = slab_floats(use_viewdirs, output_ch);
-    float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
+// stages 2 and 3: dW = dY X^T over all layers in one launch, then the fixed-order sum of the partial slabs
+static int run_dw(int64_t ldp, int use_viewdirs, int output_ch, const ParamOffsets& po, const float* act, float* scratch,
+                  float* slabs, int64_t slab, float* d_params, hipStream_t stream) {
     const int SCR_HEAD = scr_head(use_viewdirs), SCR_HEAD2 = SCR_HEAD + 32;
-
-    const size_t lds = (RING_FLOATS + AUX_FLOATS) * sizeof(float);
     hipError_t e;
-    if (use_viewdirs) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_mlp_bwd_data<true>, dim3((unsigned)blocks), dim3(THREADS), lds, stream, n_pts, 4, d_out, act,
-                           packed_fwd, packed_bwd, scratch);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_mlp_bwd_data<false>, dim3((unsigned)blocks), dim3(THREADS), lds, stream, n_pts, output_ch, d_out,
-                           act, packed_fwd, packed_bwd, scratch);
-    }
-    int rc = launched("nerf_mlp_bwd (data)");
-    if (rc) return rc;
-
+    int rc;
     // ---- dW = dY X^T: one launch over all layers
     DwTasks tk{};
     int cost[14];
@@ -580,5 +544,76 @@ int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float
     hipLaunchKernelGGL(k_reduce_slabs, dim3(1024), dim3(256), 0, stream, slabs, slab, po.total, nslabs, d_params);
     return launched("nerf_mlp_bwd (reduce)");
 }
+
+extern "C" {
+
+int64_t nerf_mlp_scratch_floats(int use_viewdirs, int64_t n_pts) { return scratch_floats(use_viewdirs, 8, n_pts); }
+
+int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                 const float* packed_fwd, const float* packed_bwd, float* scratch, float* d_params, void* stream_) {
+    (void)pts_per_ray;
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd: n_pts=%lld", (long long)n_pts);
+    NERF_REQUIRE(d_params, "nerf_mlp_bwd: null d_params");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd: output_ch=%d not in 1..8", output_ch);
+    hipStream_t stream = as_stream(stream_);
+    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
+    if (n_pts == 0) {
+        hipError_t e = hipMemsetAsync(d_params, 0, po.total * sizeof(float), stream);
+        return e == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
+    }
+    NERF_REQUIRE(d_out && act && packed_fwd && packed_bwd && scratch, "nerf_mlp_bwd: null pointer");
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch) |
+                   reinterpret_cast<uintptr_t>(packed_fwd) | reinterpret_cast<uintptr_t>(packed_bwd)) & 15) == 0,
+                 "nerf_mlp_bwd: buffers must be 16-byte aligned");
+    const int64_t ldp = padded_points(n_pts);
+    const int64_t blocks = ldp / TILE_PTS;
+    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_bwd: n_pts=%lld too large for one call", (long long)n_pts);
+    const int64_t slab = slab_floats(use_viewdirs, output_ch);
+    float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
+    const size_t lds = (RING_FLOATS + AUX_FLOATS) * sizeof(float);
+    hipError_t e;
+    if (use_viewdirs) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_mlp_bwd_data<true>, dim3((unsigned)blocks), dim3(THREADS), lds, stream, n_pts, 4, d_out, act,
+                           packed_fwd, packed_bwd, scratch);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_mlp_bwd_data<false>, dim3((unsigned)blocks), dim3(THREADS), lds, stream, n_pts, output_ch, d_out,
+                           act, packed_fwd, packed_bwd, scratch);
+    }
+    int rc = launched("nerf_mlp_bwd (data)");
+    if (rc) return rc;
+
+    return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
+}
+
+/* nerf_mlp_bwd with the backward-data stage on 16-point tiles: packed_x4 (tables behind the forward stream) and
+ * packed_bwd_x4 (nerf_pack_weights_bwd_x4) in place of the 32-point streams. */
+int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                    const float* packed_x4, const float* packed_bwd_x4, float* scratch, float* d_params, void* stream_) {
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd_x4: n_pts=%lld", (long long)n_pts);
+    NERF_REQUIRE(d_params, "nerf_mlp_bwd_x4: null d_params");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd_x4: output_ch=%d not in 1..8", output_ch);
+    hipStream_t stream = as_stream(stream_);
+    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
+    if (n_pts == 0) {
+        hipError_t e0 = hipMemsetAsync(d_params, 0, po.total * sizeof(float), stream);
+        return e0 == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd_x4: memset: %s", hipGetErrorString(e0));
+    }
+    NERF_REQUIRE(d_out && act && packed_x4 && packed_bwd_x4 && scratch, "nerf_mlp_bwd_x4: null pointer");
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch) |
+                   reinterpret_cast<uintptr_t>(packed_x4) | reinterpret_cast<uintptr_t>(packed_bwd_x4)) & 15) == 0,
+                 "nerf_mlp_bwd_x4: buffers must be 16-byte aligned");
+    const int64_t ldp = padded_points(n_pts);
+    NERF_REQUIRE(ldp / TILE_PTS <= 0x7fffffff, "nerf_mlp_bwd_x4: n_pts=%lld too large for one call", (long long)n_pts);
+    const int64_t slab = slab_floats(use_viewdirs, output_ch);
+    float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
+    int rc = nerfx4::launch_bwd_data_x4(n_pts, use_viewdirs, output_ch, d_out, act, packed_x4, packed_bwd_x4, scratch, stream);
+    if (rc) return rc;
+    return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
+}
+
 
 }  // extern "C"

@@ -329,6 +329,14 @@ int nerf_pack_weights_table(int use_viewdirs, const int32_t* table, const float*
     return launched("nerf_pack_weights_table");
 }
 
+int nerf_gather(const int32_t* table, const float* params, float* out, int64_t n, void* stream) {
+    NERF_REQUIRE(n >= 0, "nerf_gather: n=%lld", (long long)n);
+    if (n == 0) return 0;
+    NERF_REQUIRE(table && params && out, "nerf_gather: null pointer");
+    hipLaunchKernelGGL(k_pack_gather, dim3(1024), dim3(256), 0, as_stream(stream), table, params, out, n, nullptr, (int64_t)0);
+    return launched("nerf_gather");
+}
+
 int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
                  int output_ch, const float* packed_fwd, float* out, float* act, void* stream) {
     NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd: n_pts=%lld", (long long)n_pts);

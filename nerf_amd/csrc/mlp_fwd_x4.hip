@@ -13,23 +13,16 @@
 //     depend on each other (40-cycle dependent latency against 32-cycle issue);
 //   * bias = the accumulators' initial value, ReLU behind the first blocks of the next tile pair.
 #include "common.hpp"
-#include "mlp_core.hpp"
 #include "mlp_tile16.hpp"
+#include "mlp_x4.hpp"
 
 using namespace nerfhip;
 using namespace nerflayout;
 using namespace nerfmlp;
 using namespace nerftile16;
+using namespace nerfx4;
 
 namespace {
-
-constexpr int X4_THREADS = 512;
-constexpr int X4_WAVES = X4_THREADS / 64;
-constexpr int X4_WG_PTS = 16 * X4_WAVES;          // 128 points per workgroup
-constexpr int X4_SLAB = 32;                       // 1 KiB blocks per slab (16 and 64 measured 0.2 % and 1 % slower)
-constexpr int X4_SLAB_FLOATS = X4_SLAB * 256;
-constexpr int X4_RING_FLOATS = 2 * X4_SLAB_FLOATS;
-constexpr int X4_WAVE_BLOCKS = X4_SLAB / X4_WAVES;
 
 // ---- stream layout ------------------------------------------------------------------------------
 // Sections (blocks; every section starts on a slab): L0 64 (16 row tiles x 4 k-blocks of encoded position) |
@@ -83,35 +76,6 @@ __host__ __device__ inline int64_t x4_stream_source(int use_viewdirs, int output
     return -1;
 }
 
-// ---- the slab ring as one wave sees it ----------------------------------------------------------
-struct StreamX4 {
-    const float* g;   // this lane's source for block X4_WAVE_BLOCKS * wave of slab 0
-    float* ring;
-    float* mine;
-    int next, nslabs;
-    __device__ __forceinline__ void fetch(int slab) {
-        const float* src = g + (int64_t)slab * X4_SLAB_FLOATS;
-        float* dst = mine + (slab & 1) * X4_SLAB_FLOATS;
-#pragma unroll
-        for (int b = 0; b < X4_WAVE_BLOCKS; ++b) glds16(src + b * 256, dst + b * 256);
-    }
-    __device__ __forceinline__ const float* advance(int lane) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // every wave's share of slab `next` has landed; all reads of the other buffer are done
-        const float* cur = ring + (next & 1) * X4_SLAB_FLOATS + lane * 4;
-        if (next + 1 < nslabs) fetch(next + 1);
-        ++next;
-        return cur;
-    }
-};
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// An empty statement that consumes two register quads: the compiler has to place the wait for their loads here.
-__device__ __forceinline__ void need_now(const f32x4& a, const f32x4& b) { asm volatile("" ::"v"(a), "v"(b)); }
-
 // One layer: NOUT row tiles (16 features each, an even number) x NKB k-blocks (16 input features each).
 // in(kb, j) = this lane's value of input feature 16 kb + 4 g + j for its point (a register of the input array, or of
 // the encodings).  A step = the two blocks (row tiles 2u, 2u+1) of one k-block = eight MFMAs that alternate between
@@ -124,9 +88,6 @@ __device__ __forceinline__ void need_now(const f32x4& a, const f32x4& b) { asm v
 template <int NOUT, int NKB, bool RELU, bool SAVE, bool MASK, typename In>
 __device__ __forceinline__ void layer_x4(StreamX4& st, int lane, const float*& cur, In in, f32x4 (&out)[16],
                                          const float* bias_g, float* srows, uint32_t (&mb)[4]) {
-    constexpr int NS = (NOUT / 2) * NKB;
-    static_assert(NOUT % 2 == 0 && NKB >= 3, "row tiles come in pairs; the epilogue needs three steps of cover");
-    f32x4 abuf[3][2];
     auto load_bias = [&]<int U>() {
         out[2 * U] = *reinterpret_cast<const f32x4*>(bias_g + 32 * U);
         out[2 * U + 1] = *reinterpret_cast<const f32x4*>(bias_g + 32 * U + 16);
@@ -149,36 +110,7 @@ __device__ __forceinline__ void layer_x4(StreamX4& st, int lane, const float*& c
         });
     };
     if constexpr (MASK) mb[0] = mb[1] = mb[2] = mb[3] = 0u;
-    // The blocks of step s+2 are requested at the END of step s, after the wait for those of step s+1: that wait is
-    // the only one in the loop and finds reads that were issued a whole step (eight MFMAs) earlier.  Left to itself the
-    // compiler waits right before a step's first MFMA with lgkmcnt(0), i.e. also for the reads it issued one MFMA ago.
-    auto read_step = [&]<int S>() {
-        if constexpr ((2 * S) % X4_SLAB == 0) cur = st.advance(lane);
-        abuf[S % 3][0] = *reinterpret_cast<const f32x4*>(cur + ((2 * S) % X4_SLAB) * 256);
-        abuf[S % 3][1] = *reinterpret_cast<const f32x4*>(cur + ((2 * S + 1) % X4_SLAB) * 256);
-    };
-    auto await_step = [&]<int S>() { need_now(abuf[S % 3][0], abuf[S % 3][1]); };
-    load_bias.template operator()<0>();
-    read_step.template operator()<0>();
-    if constexpr (NS > 1) read_step.template operator()<1>();
-    await_step.template operator()<0>();
-    static_for<NS>([&]<int s>() {
-        constexpr int u = s / NKB, kb = s % NKB;
-        const f32x4 a0 = abuf[s % 3][0], a1 = abuf[s % 3][1];
-        static_for<4>([&]<int J>() {
-            const float x = in.template operator()<kb, J>();
-            out[2 * u] = mfma4(a0[J], x, out[2 * u]);
-            out[2 * u + 1] = mfma4(a1[J], x, out[2 * u + 1]);
-        });
-        if constexpr (kb == NKB - 2 && 2 * u + 2 < NOUT) load_bias.template operator()<u + 1>();
-        if constexpr (kb == 1 && u > 0) relu_pair.template operator()<u - 1>();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (s + 1 < NS) await_step.template operator()<s + 1>();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (s + 2 < NS) read_step.template operator()<s + 2>();
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    relu_pair.template operator()<NOUT / 2 - 1>();
+    x4_layer<NOUT, NKB>(st, lane, cur, in, out, load_bias, relu_pair);
 }
 
 // dot product of NT register tiles with a head row in LDS (natural feature order), summed over the four lane groups

@@ -6,6 +6,7 @@ if the library reports an error.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -402,12 +403,63 @@ def mlp_backward(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, pac
     return d_flat
 
 
+def pack_weights_bwd_x4(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    flat = _f32c(flat, "params")
+    assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
+    out = torch.empty(lib.nerf_mlp_packed_bwd_x4_floats(int(use_viewdirs)), dtype=torch.float32, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_pack_weights_bwd_x4(int(use_viewdirs), output_ch, flat.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def x4_pack_table(use_viewdirs: bool, output_ch: int, dev):
+    """(int32 source map of the forward 16-point stream followed by the transposed one, length of the first): the
+    packing kernels run once on the vector 1, 2, 3, ... (exact in fp32: a network has under 2^24 parameters)."""
+    n = mlp_n_params(use_viewdirs, output_ch)
+    assert n < (1 << 24)
+    ramp = torch.arange(1, n + 1, dtype=torch.float32, device=dev)
+    a = pack_weights_x4(ramp, use_viewdirs, output_ch)
+    b = pack_weights_bwd_x4(ramp, use_viewdirs, output_ch)
+    assert a.numel() % 4 == 0   # the second stream starts 16-byte aligned
+    return (torch.cat([a, b]).to(torch.int32) - 1).contiguous(), a.numel()
+
+
+def pack_weights_x4_pair(flat: torch.Tensor, table: torch.Tensor, n_fwd: int):
+    flat = _f32c(flat, "params")
+    out = torch.empty(table.numel(), dtype=torch.float32, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_gather(table.data_ptr(), flat.data_ptr(), out.data_ptr(), table.numel(), _stream()))
+    return out[:n_fwd], out[n_fwd:]
+
+
+def mlp_backward_x4(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x4: torch.Tensor,
+                    packed_bwd_x4: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    """mlp_backward with the backward-data stage on 16-point tiles."""
+    d_out = _f32c(d_out, "d_out")
+    n_pts = d_out.shape[0]
+    scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
+    d_flat = torch.empty_like(flat)
+    with torch.cuda.device(d_out.device), _timed("mlp_bwd", n_pts):
+        check(lib.nerf_mlp_bwd_x4(n_pts, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
+                                  packed_x4.data_ptr(), packed_bwd_x4.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(),
+                                  _stream()))
+    return d_flat
+
+
+# backward-data stage on 16-point tiles (NERF_BWD_X4=0 selects the 32-point kernel, kept for A/B runs)
+BWD_X4 = os.environ.get("NERF_BWD_X4", "1") != "0"
+
+
 class _FusedMLP(torch.autograd.Function):
     """raw = NeRF(encode(pts), encode(viewdirs)); gradients flow to the parameters only."""
 
     @staticmethod
     def forward(ctx, pts, viewdirs, model, pts_per_ray, need_grad, *params):
-        fwd, bwd, flat = model._packed(need_grad)
+        x4b = need_grad and BWD_X4
+        flat = model._flat()
+        fwd = bwd = None
+        if pts_per_ray == 0 or (need_grad and not x4b):
+            fwd, bwd, flat = model._packed(need_grad and not x4b)
         n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
         if pts_per_ray > 0:   # raw positions: the 16-point-tile kernel (the 32-point one serves pre-encoded inputs)
@@ -415,7 +467,10 @@ class _FusedMLP(torch.autograd.Function):
         else:
             out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
         if need_grad:
+            if x4b:   # the streams the 16-point-tile backward reads, in the slots of the 32-point ones
+                fwd, bwd = model._packed_x4(), model._packed_bwd_x4()
             ctx.save_for_backward(act, fwd, bwd, flat)
+            ctx.x4b = x4b
             ctx.model = model
             ctx.pts_per_ray = pts_per_ray
         return out
@@ -424,7 +479,10 @@ class _FusedMLP(torch.autograd.Function):
     def backward(ctx, d_out):
         act, fwd, bwd, flat = ctx.saved_tensors
         model = ctx.model
-        d_flat = mlp_backward(d_out, act, flat, bwd, fwd, model.use_viewdirs, model.output_ch, ctx.pts_per_ray)
+        if ctx.x4b:
+            d_flat = mlp_backward_x4(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
+        else:
+            d_flat = mlp_backward(d_out, act, flat, bwd, fwd, model.use_viewdirs, model.output_ch, ctx.pts_per_ray)
         grads = model._split_flat(d_flat)
         return (None, None, None, None, None) + tuple(grads)
 

@@ -95,6 +95,8 @@ class NeRF(nn.Module):
         self._pack_table = None
         self._pack16 = None
         self._packx4 = None
+        self._x4_table = None
+        self._flat_vec = None
         # 'f32' (default; fp32 MFMA, the reference's precision) or 'bf16' (no-grad queries only: bf16 operands,
         # fp32 accumulation, raw outputs within ~1e-2 of their scale; training always runs fp32)
         self.mlp_dtype = 'f32'
@@ -113,35 +115,51 @@ class NeRF(nn.Module):
                 f"input_ch_views={self.input_ch_views}, use_viewdirs={self.use_viewdirs}): the fused HIP kernel "
                 "implements D=8, W=256, skips=[4], input_ch=63 and input_ch_views=27 (or 0 without view directions)")
 
-    def _packed(self, want_bwd: bool):
-        """(forward stream, backward stream or None, flat parameters); repacked when a parameter changed."""
+    def _flat(self) -> torch.Tensor:
+        """The parameters as one flat vector (state_dict order); every packed stream is dropped when a parameter
+        changed (in-place updates bump the tensors' version counters)."""
         self._check_arch()
         params = list(self.parameters())
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._pack is None or self._pack_key != key or (want_bwd and self._pack[1] is None):
+        if self._flat_vec is None or self._pack_key != key:
             with torch.no_grad():
                 flat = torch.cat([p.detach().reshape(-1) for p in params])
-                if not flat.is_cuda:
-                    raise RuntimeError("NeRF parameters must live on a HIP device (call .to('cuda'))")
-                if self._pack_table is None or self._pack_table.device != flat.device:
-                    self._pack_table = ops.pack_table(self.use_viewdirs, self.output_ch, flat.device)
-                fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd, self._pack_table)
-            self._pack, self._pack_key = (fwd, bwd, flat), key
-            self._pack16 = None
-            self._packx4 = None
+            if not flat.is_cuda:
+                raise RuntimeError("NeRF parameters must live on a HIP device (call .to('cuda'))")
+            self._flat_vec, self._pack_key = flat, key
+            self._pack = self._pack16 = self._packx4 = None
+        return self._flat_vec
+
+    def _packed(self, want_bwd: bool):
+        """(forward stream, backward stream or None, flat parameters) of the 32-point-tile kernels."""
+        flat = self._flat()
+        if self._pack is None or (want_bwd and self._pack[1] is None):
+            if self._pack_table is None or self._pack_table.device != flat.device:
+                self._pack_table = ops.pack_table(self.use_viewdirs, self.output_ch, flat.device)
+            fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd, self._pack_table)
+            self._pack = (fwd, bwd, flat)
         return self._pack
 
     def _packed_bf16(self):
-        flat = self._packed(False)[2]
+        flat = self._flat()
         if self._pack16 is None:
             self._pack16 = ops.pack_weights_bf16(flat, self.use_viewdirs, self.output_ch)
         return self._pack16
 
-    def _packed_x4(self):
-        flat = self._packed(False)[2]
+    def _packed_x4_pair(self):
+        """(forward stream, transposed stream) of the 16-point-tile kernels: one gather through a map built once."""
+        flat = self._flat()
         if self._packx4 is None:
-            self._packx4 = ops.pack_weights_x4(flat, self.use_viewdirs, self.output_ch)
+            if self._x4_table is None or self._x4_table[0].device != flat.device:
+                self._x4_table = ops.x4_pack_table(self.use_viewdirs, self.output_ch, flat.device)
+            self._packx4 = ops.pack_weights_x4_pair(flat, *self._x4_table)
         return self._packx4
+
+    def _packed_x4(self):
+        return self._packed_x4_pair()[0]
+
+    def _packed_bwd_x4(self):
+        return self._packed_x4_pair()[1]
 
     def _split_flat(self, flat: torch.Tensor):
         out, off = [], 0

@@ -451,7 +451,10 @@ def _grad_close(got, want, what, rtol=2e-3, atol_frac=2e-5):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_frac * scale, err_msg=what)
 
 
-def test_mlp_backward_matches_reference_and_oracle(device):
+@pytest.mark.parametrize("bwd_x4", [True, False], ids=["bwd16", "bwd32"])
+def test_mlp_backward_matches_reference_and_oracle(device, monkeypatch, bwd_x4):
+    from nerf_amd import ops
+    monkeypatch.setattr(ops, "BWD_X4", bwd_x4)   # backward-data stage on 16-point or on 32-point tiles
     g = golden("mlp")
     qf = _query_fn()
     sd = O.random_state_dict(21)
@@ -497,8 +500,11 @@ def _relu_margin(sd, pts, vd, use_vd):
     return margin.reshape(pts.shape[:-1])
 
 
-def test_mlp_backward_sizes_and_no_view_branch(device):
+@pytest.mark.parametrize("bwd_x4", [True, False], ids=["bwd16", "bwd32"])
+def test_mlp_backward_sizes_and_no_view_branch(device, monkeypatch, bwd_x4):
     """Ragged point counts (tile padding, empty K slices) and the output_linear head, against oracle autograd."""
+    from nerf_amd import ops
+    monkeypatch.setattr(ops, "BWD_X4", bwd_x4)
     rng = np.random.Generator(np.random.PCG64(10))
     qf = _query_fn()
     for use_vd, n, s in ((True, 3, 5), (True, 70, 64), (False, 33, 8)):
