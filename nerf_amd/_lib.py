@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  isort: skip
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
+# NERF_HIP_LIB names another build of the same library (A/B runs of kernel variants on one box)
+LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "libnerf_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

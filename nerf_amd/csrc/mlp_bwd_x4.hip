@@ -82,7 +82,7 @@ __device__ __forceinline__ void layer_x4b(StreamX4& st, int lane, int g, const f
                     out[t][i] = __uint_as_float(__float_as_uint(out[t][i]) & m);
                 }
             }
-            *reinterpret_cast<f32x4*>(srows + 4 * t * GROUP_FLOATS) = out[t];
+            save16(srows + 4 * t * GROUP_FLOATS, out[t]);
         });
     };
     x4_layer<NOUT, NKB>(st, lane, cur, in, out, start, finish);
@@ -155,7 +155,7 @@ k_mlp_bwd_data_x4(int64_t n_pts, int output_ch, const float* __restrict__ d_out,
                 const float v = fmaf(w2[i], gd[2], fmaf(w1[i], gd[1], w0[i] * gd[0]));
                 P[t][i] = on(m8, t, i) ? v : 0.0f;
             }
-            *reinterpret_cast<f32x4*>(rows(SCR_VIEWS) + 4 * t * GROUP_FLOATS) = P[t];
+            save16(rows(SCR_VIEWS) + 4 * t * GROUP_FLOATS, P[t]);
         }
         // d(feature) = Wviews[:, :256]^T dY_views -> Q (feature_linear has no activation)
         layer_x4b<16, 8, false, false>(st, lane, g, cur, inP, Q, nullptr, 0.0f, none, rows(SCR_FEAT));
@@ -183,7 +183,7 @@ k_mlp_bwd_data_x4(int64_t n_pts, int output_ch, const float* __restrict__ d_out,
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) P[t][i] = on(m7, t, i) ? v[i] : 0.0f;
-            *reinterpret_cast<f32x4*>(rows(SCR_H0 + 7 * 256) + 4 * t * GROUP_FLOATS) = P[t];
+            save16(rows(SCR_H0 + 7 * 256) + 4 * t * GROUP_FLOATS, P[t]);
         }
     }
 

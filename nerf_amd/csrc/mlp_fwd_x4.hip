@@ -106,7 +106,7 @@ __device__ __forceinline__ void layer_x4(StreamX4& st, int lane, const float*& c
                     }
                 }
             }
-            if constexpr (SAVE) *reinterpret_cast<f32x4*>(srows + 4 * t * GROUP_FLOATS) = out[t];
+            if constexpr (SAVE) save16(srows + 4 * t * GROUP_FLOATS, out[t]);
         });
     };
     if constexpr (MASK) mb[0] = mb[1] = mb[2] = mb[3] = 0u;

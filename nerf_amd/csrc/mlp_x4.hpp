@@ -47,6 +47,10 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 16-byte store of a finished tile to the saved activations / gradient workspace (a non-temporal store measured the
+// same: +0.1 % on the train step)
+__device__ __forceinline__ void save16(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+
 // An empty statement that consumes two register quads: the compiler has to place the wait for their loads here.
 __device__ __forceinline__ void need_now(const f32x4& a, const f32x4& b) { asm volatile("" ::"v"(a), "v"(b)); }
 
