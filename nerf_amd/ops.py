@@ -278,6 +278,15 @@ def composite(raw, z, rays_d, noise=None, white_bkgd=False):
     channels 0..3 are read, and the others receive a zero gradient."""
     _no_input_grad(z, "composite: z")
     _no_input_grad(rays_d, "composite: rays_d")
+    if z.shape[-1] == 1:
+        # One sample per ray: upstream's appended 1e10 gap takes the (empty) shape of the other gaps
+        # (run_nerf.py:309-311), every per-sample product broadcasts to zero samples, and the sums run over nothing:
+        # no weights, acc = 0, rgb = background, disp = 1 / max(1e-10, 0 / 0) = NaN.  No kernel has anything to do.
+        n, dev = z.shape[0], z.device
+        acc = torch.zeros(n, dtype=torch.float32, device=dev)
+        rgb = torch.full((n, 3), 1.0 if white_bkgd else 0.0, dtype=torch.float32, device=dev)
+        return (rgb, torch.full_like(acc, float("nan")), acc, torch.zeros((n, 0), dtype=torch.float32, device=dev),
+                torch.zeros_like(acc))
     if raw.shape[-1] > 4:
         raw = raw[..., :4]
     return _Composite.apply(raw, z, rays_d, noise, white_bkgd)
