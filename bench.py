@@ -148,7 +148,7 @@ def hbm_kernels(prof):
                 "frac_of_hbm_peak": round(b / t / 1e9 / HBM_PEAK_GBS, 4)} for k, (b, t, c) in agg.items() if t > 0}
 
 
-def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=False):
+def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=False, scene="lego"):
     """The upstream optimisation step (run_nerf.py:826-883, no_batching mode) on synthetic targets: rays of one
     400x400 view, n_rand random pixels, render with jitter, two MSE terms, backward, (all-reduce,) Adam, lr decay.
     graphed: the same step recorded into HIP graphs after three eager steps and replayed (nerf_amd.graph_step)."""
@@ -158,6 +158,14 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     H = W = 400
     K = lego_camera(H, W)
     kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
+    if scene == "fern":
+        # configs/fern.txt on the survey's LLFF intrinsics: 378 x 504, focal 407.57, forward-facing poses, NDC rays
+        # (near 0, far 1), density noise 1.0, 64 + 64 samples, black background
+        H, W = 378, 504
+        K = np.array([[407.5658, 0, 0.5 * W], [0, 407.5658, 0.5 * H], [0, 0, 1]])
+        kw = dict(kwargs, perturb=1.0, raw_noise_std=1.0, N_importance=64, white_bkgd=False, near=0., far=1., lindisp=False)
+        del kw["ndc"]     # as upstream's create_nerf leaves it for LLFF: render() defaults to ndc=True
+    pts_per_ray = 2 * kw["N_samples"] + kw["N_importance"]
     params = list(models[0].parameters()) + list(models[1].parameters())
     saved = [p.detach().clone() for p in params]
     opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=graphed)
@@ -171,6 +179,9 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     gen.manual_seed(seed)
     thetas = np.linspace(-180, 180, 41)[:-1]
     poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(max(warmup, 5) + steps)]
+    if scene == "fern":   # cameras at z ~ 0 looking down -z, shifted sideways along a line
+        poses = [torch.tensor([[1., 0, 0, 0.2 * np.sin(0.7 * i)], [0, 1., 0, 0.1 * np.cos(0.7 * i)], [0, 0, 1., 0.05 * i % 0.3]],
+                              dtype=torch.float32, device=dev) for i in range(len(poses))]
     target_img = torch.rand(H * W, 3, device=dev, generator=gen)
 
     def one(i):
@@ -217,12 +228,12 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
         m._pack_key = None
     if graphed:
         return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
-                "n_rand_per_gpu": n_rand, "steps": steps, "final_loss": float(loss),
+                "n_rand_per_gpu": n_rand, "steps": steps, "final_loss": float(loss.detach()),
                 "note": "the same step replayed from two HIP graphs (render+loss+backward | Adam)"}
     kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in ("mlp_fwd_save", "mlp_bwd"))
-    flop = n_rand * 256 * FLOP_PER_POINT_TRAIN * steps
+    flop = n_rand * pts_per_ray * FLOP_PER_POINT_TRAIN * steps
     return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "n_rand_per_gpu": n_rand,
-            "steps": steps, "final_loss": float(loss), "mlp_kernels_share_of_step": round(kern / dt, 4),
+            "points_per_ray": pts_per_ray, "steps": steps, "final_loss": float(loss.detach()), "mlp_kernels_share_of_step": round(kern / dt, 4),
             "mlp_tflops_algorithmic": round(flop / kern / 1e12, 2) if kern > 0 else None,
             "frac_of_fp32_matrix_peak": round(flop / kern / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if kern > 0 else None,
             "hbm_kernels": hbm_kernels(prof)}
@@ -381,6 +392,11 @@ def main():
                 out[key] = time_train(models, kwargs, dev, world, n_rand, k, w, seed=seed + rank)
             except Exception as exc:  # the headline number must survive a failure of an extra
                 out[key] = {"error": repr(exc)}
+        if world == 1:   # configs[2]: fern-shaped step (NDC, density noise, 64 + 64 samples), single-GPU extra
+            try:
+                out["train_fern"] = time_train(models, kwargs, dev, world, 1024, 10, 3, seed=99, scene="fern")
+            except Exception as exc:
+                out["train_fern"] = {"error": repr(exc)}
         if world == 1:   # single-GPU extra; the multi-rank runs keep to the eager step
             try:
                 out["train_graphed"] = time_train(models, kwargs, dev, world, 1024, 10, 5, seed=1234 + rank, graphed=True)
