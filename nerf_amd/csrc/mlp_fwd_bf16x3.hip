@@ -1,0 +1,385 @@
+// Fused positional encoding + NeRF MLP forward with fp32 accuracy on the bf16 matrix instruction.
+//
+// Every fp32 operand is split EXACTLY into three bf16 pieces, x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid): 3 x 8 significant bits = the 24 of an fp32), and a product a.b is rebuilt from the six
+// largest of the nine piece products -- hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid -- each exact in the fp32
+// accumulator's input; the three dropped ones are below 2^-24 of the product, the size of one fp32 rounding.  A 256-term
+// dot product built this way measures the same error against fp64 as v_mfma_f32_16x16x4_f32 does (rms 1.9e-8 against
+// 2.4e-8 of sum |a||b|, tools/probe_bf16x3.hip), and six v_mfma_f32_16x16x32_bf16 cost 6/16 of the fp32 instructions
+// they replace.
+//
+// Dataflow as in mlp_fwd_bf16.hip (activations never leave the register file; weights stream through an LDS slab
+// ring; bias = accumulator start value; a tile's epilogue -- ReLU, heads, the three-way split of its values -- rides
+// behind the next tile's MFMAs), with
+//   * three A fragments per weight block (a "triple": hi | mid | lo, 3 KiB), split once per weight update by the packer;
+//   * three B fragments per activation k-step and column tile: 2 x 192 registers for the two activation arrays, so ONE
+//     wave per SIMD (up to 512 registers), four waves and 128 points per workgroup;
+//   * twelve MFMAs per triple (six products x two column tiles) that alternate between the column tiles' accumulators.
+#include "common.hpp"
+#include "mlp_core.hpp"
+#include "mlp_tile16.hpp"
+#include "mlp_bf16_layout.hpp"
+
+using namespace nerfhip;
+using namespace nerflayout;
+using namespace nerfmlp;
+using namespace nerftile16;
+using namespace nerfbf16;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NCT = 2;                         // 16-point column tiles per wave
+constexpr int X3_THREADS = 256;                // four waves, one per SIMD
+constexpr int X3_WAVES = X3_THREADS / 64;
+constexpr int WAVE_PTS = 16 * NCT;
+constexpr int X3_WG_PTS = X3_WAVES * WAVE_PTS; // 128 points per workgroup
+constexpr int TRIPLE_BYTES = 3 * 1024;
+constexpr int SLABT = 8;                       // triples per slab (every section of the stream is a multiple of 8)
+constexpr int SLAB3_BYTES = SLABT * TRIPLE_BYTES;
+constexpr int RING3_BYTES = 2 * SLAB3_BYTES;
+constexpr int WAVE_BLOCKS3 = SLABT * 3 / X3_WAVES;   // 1 KiB blocks each wave fetches per slab
+
+__host__ __device__ inline int x3_stream_slabs(int use_viewdirs) { return bf16_stream_blocks(use_viewdirs) / SLABT; }
+__host__ __device__ inline int64_t x3_packed_bytes(int use_viewdirs) {
+    return (int64_t)x3_stream_slabs(use_viewdirs) * SLAB3_BYTES + (int64_t)AUX16_FLOATS * 4;
+}
+
+// x = hi + mid + lo, exactly (each difference of an fp32 and its bf16 rounding is an fp32)
+__host__ __device__ inline void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
+struct Stream3 {
+    const char* g;   // this lane's source for block WAVE_BLOCKS3 * wave of slab 0
+    char* ring;
+    char* mine;
+    int next, nslabs;
+    __device__ __forceinline__ void fetch(int slab) {
+        const char* src = g + (int64_t)slab * SLAB3_BYTES;
+        char* dst = mine + (slab & 1) * SLAB3_BYTES;
+#pragma unroll
+        for (int b = 0; b < WAVE_BLOCKS3; ++b)
+            glds16(reinterpret_cast<const float*>(src + b * 1024), reinterpret_cast<float*>(dst + b * 1024));
+    }
+    __device__ __forceinline__ const char* advance(int lane) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* cur = ring + (next & 1) * SLAB3_BYTES + lane * 16;
+        if (next + 1 < nslabs) fetch(next + 1);
+        ++next;
+        return cur;
+    }
+};
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// (weight piece, activation piece) of the six products, smallest first
+constexpr int PROD_W[6] = {1, 2, 0, 1, 0, 0};
+constexpr int PROD_X[6] = {1, 0, 2, 0, 1, 0};
+
+// eight fp32 values -> the three bf16 fragments of their pieces
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 h, m, l;
+        split3(v[i], h, m, l);
+        hi[i] = h; mid[i] = m; lo[i] = l;
+    }
+}
+
+// One layer: NOUT row tiles (16 features each) x NKS k-steps (32 input features each) x NCT column tiles.
+// in_frag<CT, ks, S>() = piece S of the input fragment of column tile CT, k-step ks.  Y[S][CT][..] receives the pieces
+// of the output (STORE).  Everything else as layer16 of mlp_fwd_bf16.hip.
+template <int NOUT, int NKS, int NHEAD, bool STORE, typename InFrag>
+__device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const char*& cur, InFrag in_frag,
+                                         bf16x8 (&Y)[3][NCT][8], const float* bias_lds, float lo, const float* head_lds,
+                                         int head_stride, float (&head)[NCT][3]) {
+    constexpr int NB = NOUT * NKS, DEPTH = 3, NPIECE = 2 * NCT;
+    constexpr bool BIAS_INIT = NKS >= 7;
+    constexpr int PPS = (NPIECE + (NKS < 8 ? NKS : 8) - 1) / (NKS < 8 ? NKS : 8);   // epilogue pieces per k-step
+    bf16x8 abuf[DEPTH + 1][3];
+    f32x4 acc[2][NCT];                            // [alternating set][column tile]
+    const float* bp = bias_lds + 4 * g;
+    const float* hp = head_lds + 4 * g;
+
+    auto load_bias = [&]<int TO>() {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + 16 * TO);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[TO & 1][ct] = bb;
+    };
+    auto piece = [&]<int TP, int K>() {           // K = 2 * column tile + register pair
+        constexpr int ct = K >> 1, pr = K & 1;
+        float v0 = acc[TP & 1][ct][2 * pr], v1 = acc[TP & 1][ct][2 * pr + 1];
+        if constexpr (!BIAS_INIT) {
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(bp + 16 * TP + 2 * pr);
+            v0 += bb[0];
+            v1 += bb[1];
+        }
+        v0 = fmaxf(v0, lo);
+        v1 = fmaxf(v1, lo);
+#pragma unroll
+        for (int k = 0; k < NHEAD; ++k) {
+            const f32x2 w = *reinterpret_cast<const f32x2*>(hp + k * head_stride + 16 * TP + 2 * pr);
+            head[ct][k] = fmaf(v1, w[1], fmaf(v0, w[0], head[ct][k]));
+            asm volatile("" : "+v"(head[ct][k]));   // keep the head sums here (see mlp_fwd_bf16.hip)
+        }
+        if constexpr (STORE) {
+            constexpr int f = TP >> 1, s0 = 4 * (TP & 1) + 2 * pr;
+            __bf16 h, m, l;
+            split3(v0, h, m, l);
+            Y[0][ct][f][s0] = h; Y[1][ct][f][s0] = m; Y[2][ct][f][s0] = l;
+            split3(v1, h, m, l);
+            Y[0][ct][f][s0 + 1] = h; Y[1][ct][f][s0 + 1] = m; Y[2][ct][f][s0 + 1] = l;
+        }
+    };
+
+    if constexpr (BIAS_INIT) load_bias.template operator()<0>();
+    static_for<NB + DEPTH>([&]<int I>() {
+        if constexpr (I < NB) {
+            if constexpr (I % SLABT == 0) cur = st.advance(lane);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                abuf[I % (DEPTH + 1)][s] = *reinterpret_cast<const bf16x8*>(cur + (I % SLABT) * TRIPLE_BYTES + s * 1024);
+        }
+        if constexpr (I >= DEPTH) {
+            constexpr int b = I - DEPTH;
+            constexpr int to = b / NKS, ks = b % NKS;
+            static_for<6>([&]<int P>() {
+                constexpr int pw = PROD_W[P], px = PROD_X[P];
+                const bf16x8 a = abuf[b % (DEPTH + 1)][pw];
+                static_for<NCT>([&]<int CT>() {
+                    const bf16x8 x = in_frag.template operator()<CT, ks, px>();
+                    if constexpr (!BIAS_INIT && ks == 0 && P == 0) {
+                        const f32x4 zero = {0, 0, 0, 0};
+                        acc[to & 1][CT] = mfma16(a, x, zero);
+                    } else {
+                        acc[to & 1][CT] = mfma16(a, x, acc[to & 1][CT]);
+                    }
+                });
+            });
+            if constexpr (to > 0) {   // the previous row tile's epilogue, piece by piece, behind this tile's MFMAs
+                static_for<PPS>([&]<int Q>() {
+                    constexpr int K = ks * PPS + Q;
+                    if constexpr (K < NPIECE) piece.template operator()<to - 1, K>();
+                });
+            }
+            if constexpr (BIAS_INIT && to + 1 < NOUT && ks == NKS - 3) load_bias.template operator()<to + 1>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<NPIECE>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
+}
+
+template <bool VIEWDIRS>
+__global__ void __launch_bounds__(X3_THREADS, 1)
+k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
+                 int output_ch, const char* __restrict__ packed, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    char* ring = smem3;
+    float* aux = reinterpret_cast<float*>(smem3 + RING3_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    constexpr int UV = VIEWDIRS ? 1 : 0;
+    {
+        const float* gaux = reinterpret_cast<const float*>(packed + (int64_t)x3_stream_slabs(UV) * SLAB3_BYTES);
+        for (int i = tid * 4; i < AUX16_FLOATS; i += X3_THREADS * 4)
+            *reinterpret_cast<f32x4*>(aux + i) = *reinterpret_cast<const f32x4*>(gaux + i);
+    }
+
+    // ---- encodings, split, parked in LDS: fragment (piece s, slot f) of this lane at ed[(s * NF + f) * 64],
+    // f = 2 ct + k-step for the position, 2 NCT + ct for the direction
+    constexpr int NF = 3 * NCT;
+    bf16x8* ed = reinterpret_cast<bf16x8*>(smem3 + RING3_BYTES + AUX16_FLOATS * 4) + wave * (3 * NF * 64) + lane;
+    auto park = [&](int f, const float* v) {
+        bf16x8 h, m, l;
+        split8(v, h, m, l);
+        ed[(0 * NF + f) * 64] = h;
+        ed[(1 * NF + f) * 64] = m;
+        ed[(2 * NF + f) * 64] = l;
+    };
+    int64_t p[NCT];
+    bool valid[NCT];
+    const int c0 = enc16_first_pair(g);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        p[ct] = (int64_t)blockIdx.x * X3_WG_PTS + wave * WAVE_PTS + ct * 16 + (lane & 15);
+        valid[ct] = p[ct] < n_pts;
+        const int64_t pl = valid[ct] ? p[ct] : n_pts - 1;
+        const float x0 = pts[pl * 3 + 0], x1 = pts[pl * 3 + 1], x2 = pts[pl * 3 + 2];
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i, k = c / 3, d = c - 3 * k;   // (groups 2, 3: pair 7 is overwritten below)
+            const float arg = (d == 0 ? x0 : (d == 1 ? x1 : x2)) * __int_as_float((127 + k) << 23);
+            sincosf(arg, &e[2 * i], &e[2 * i + 1]);
+        }
+        if (g == 2) { e[14] = x0; e[15] = x1; }
+        if (g == 3) { e[14] = x2; e[15] = 0.0f; }
+        park(2 * ct + 0, e);
+        park(2 * ct + 1, e + 8);
+        if (VIEWDIRS) {
+            const int64_t ray = pl / pts_per_ray;
+            const float v0 = viewdirs[ray * 3 + 0], v1 = viewdirs[ray * 3 + 1], v2 = viewdirs[ray * 3 + 2];
+            float dd[8];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = 3 * g + i, k = c / 3, d = c - 3 * k;
+                const float arg = (d == 0 ? v0 : (d == 1 ? v1 : v2)) * __int_as_float((127 + k) << 23);
+                sincosf(arg, &dd[2 * i], &dd[2 * i + 1]);
+            }
+            dd[6] = g == 0 ? v0 : (g == 1 ? v2 : 0.0f);
+            dd[7] = g == 0 ? v1 : 0.0f;
+            park(2 * NCT + ct, dd);
+        }
+    }
+
+    Stream3 st;
+    st.ring = ring;
+    st.mine = ring + wave * WAVE_BLOCKS3 * 1024;
+    st.g = packed + wave * WAVE_BLOCKS3 * 1024 + lane * 16;
+    st.next = 0;
+    st.nslabs = x3_stream_slabs(UV);
+    __syncthreads();
+    st.fetch(0);
+    const char* cur = nullptr;
+
+    bf16x8 X[3][NCT][8], Y[3][NCT][8];
+    float sig[NCT][3], rgb[NCT][3];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sig[ct][k] = rgb[ct][k] = 0.0f;
+    const float NOCLAMP = -__builtin_inff();
+    const float* bias = aux + AUX16_BIAS;
+    const float* hw = aux + AUX16_HEAD;
+    auto fromE = [&]<int ct, int ks, int s>() -> bf16x8 { return ed[(s * NF + 2 * ct + ks) * 64]; };
+    auto fromX = [&]<int ct, int ks, int s>() -> bf16x8 { return X[s][ct][ks]; };
+    auto fromY = [&]<int ct, int ks, int s>() -> bf16x8 { return Y[s][ct][ks]; };
+    auto fromXE = [&]<int ct, int ks, int s>() -> bf16x8 {
+        if constexpr (ks < 8) return X[s][ct][ks]; else return ed[(s * NF + 2 * ct + ks - 8) * 64];
+    };
+    auto fromXD = [&]<int ct, int ks, int s>() -> bf16x8 {
+        if constexpr (ks < 8) return X[s][ct][ks]; else return ed[(s * NF + 2 * NCT + ct) * 64];
+    };
+
+    layer_x3<16, 2, 0, true>(st, lane, g, cur, fromE, X, bias, 0.0f, hw, 0, sig);                    // L0
+    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromX, Y, bias + 1 * 256, 0.0f, hw, 0, sig);          // L1
+    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 2 * 256, 0.0f, hw, 0, sig);          // L2
+    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromX, Y, bias + 3 * 256, 0.0f, hw, 0, sig);          // L3
+    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 4 * 256, 0.0f, hw, 0, sig);          // L4
+    layer_x3<16, 10, 0, true>(st, lane, g, cur, fromXE, Y, bias + 5 * 256, 0.0f, hw, 0, sig);        // L5 (skip)
+    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 6 * 256, 0.0f, hw, 0, sig);          // L6
+    auto over_groups = [](float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
+    if constexpr (VIEWDIRS) {
+        layer_x3<16, 8, 1, true>(st, lane, g, cur, fromX, Y, bias + 7 * 256, 0.0f, hw, 0, sig);      // L7 + alpha head
+        layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 8 * 256, NOCLAMP, hw, 0, sig);   // feature
+        layer_x3<8, 9, 3, false>(st, lane, g, cur, fromXD, Y, bias + 9 * 256, 0.0f, hw + 256, 128, rgb);   // views + rgb heads
+        const float* hb = hw + 256 + 384;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = over_groups(rgb[ct][k]) + hb[1 + k];
+            o[3] = over_groups(sig[ct][0]) + hb[0];
+            if (valid[ct] && g == (ct & 3)) *reinterpret_cast<f32x4*>(out + p[ct] * 4) = o;
+        }
+    } else {
+        // output_linear: rows 0..2 as fp32 head dot products inside the L7 epilogue, rows 3..7 from the pieces afterwards
+        layer_x3<16, 8, 3, true>(st, lane, g, cur, fromX, Y, bias + 7 * 256, 0.0f, hw, 256, sig);
+        for (int ch = 0; ch < output_ch; ++ch) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                float s;
+                if (ch < 3) {
+                    s = ch == 0 ? sig[ct][0] : (ch == 1 ? sig[ct][1] : sig[ct][2]);
+                } else {
+                    const float* wp = hw + ch * 256;
+                    s = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float y = ((float)Y[0][ct][ks][j] + (float)Y[1][ct][ks][j]) + (float)Y[2][ct][ks][j];
+                            s = fmaf(y, wp[32 * ks + kslot_feature(g, j)], s);
+                        }
+                }
+                s = over_groups(s) + hw[8 * 256 + ch];
+                if (valid[ct] && g == (ct & 3)) out[p[ct] * output_ch + ch] = s;
+            }
+        }
+    }
+}
+
+// flat parameters -> stream of triples + fp32 aux tables
+__global__ void __launch_bounds__(256) k_pack_bf16x3(int use_viewdirs, int output_ch, const float* __restrict__ params,
+                                                     char* __restrict__ out) {
+    const int64_t ntriples = bf16_stream_blocks(use_viewdirs);
+    const int64_t elems = ntriples * 512;           // one per (triple, lane, slot)
+    const int64_t total = elems + AUX16_FLOATS;
+    unsigned short* s16 = reinterpret_cast<unsigned short*>(out);
+    float* aux = reinterpret_cast<float*>(out + ntriples * TRIPLE_BYTES);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < elems) {
+            const int64_t t = i >> 9;
+            const int w = (int)(i & 511);
+            const int64_t src = bf16_stream_source(use_viewdirs, output_ch, (int)t, w >> 3, w & 7);
+            __bf16 h, m, l;
+            split3(src < 0 ? 0.0f : params[src], h, m, l);
+            unsigned short* dst = s16 + t * (TRIPLE_BYTES / 2) + w;
+            dst[0] = __builtin_bit_cast(unsigned short, h);
+            dst[512] = __builtin_bit_cast(unsigned short, m);
+            dst[1024] = __builtin_bit_cast(unsigned short, l);
+        } else {
+            const int64_t src = aux16_source(use_viewdirs, output_ch, (int)(i - elems));
+            aux[i - elems] = src < 0 ? 0.0f : params[src];
+        }
+    }
+}
+
+constexpr size_t X3_LDS_BYTES = RING3_BYTES + AUX16_FLOATS * sizeof(float) + X3_WAVES * 3 * 3 * NCT * 64 * 16;
+
+}  // namespace
+
+extern "C" {
+
+int64_t nerf_mlp_packed_bf16x3_bytes(int use_viewdirs) { return x3_packed_bytes(use_viewdirs); }
+
+int nerf_pack_weights_bf16x3(int use_viewdirs, int output_ch, const float* params, void* packed, void* stream) {
+    NERF_REQUIRE(params && packed, "nerf_pack_weights_bf16x3: null pointer");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_pack_weights_bf16x3: output_ch=%d not in 1..8", output_ch);
+    hipLaunchKernelGGL(k_pack_bf16x3, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, params,
+                       reinterpret_cast<char*>(packed));
+    return launched("nerf_pack_weights_bf16x3");
+}
+
+int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
+                        int output_ch, const void* packed, float* out, void* stream) {
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd_bf16x3: n_pts=%lld", (long long)n_pts);
+    if (n_pts == 0) return 0;
+    NERF_REQUIRE(pts && packed && out, "nerf_mlp_fwd_bf16x3: null pointer");
+    NERF_REQUIRE(!use_viewdirs || (viewdirs && pts_per_ray >= 1), "nerf_mlp_fwd_bf16x3: view branch needs viewdirs and pts_per_ray >= 1");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_fwd_bf16x3: output_ch=%d not in 1..8", output_ch);
+    NERF_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                 "nerf_mlp_fwd_bf16x3: packed and out must be 16-byte aligned");
+    const int64_t blocks = (n_pts + X3_WG_PTS - 1) / X3_WG_PTS;
+    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_bf16x3: n_pts=%lld too large for one launch", (long long)n_pts);
+    auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)X3_LDS_BYTES);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), X3_LDS_BYTES, as_stream(stream), n_pts, ppr, pts,
+                           vd, och, reinterpret_cast<const char*>(packed), out);
+        return launched("nerf_mlp_fwd_bf16x3");
+    };
+    if (use_viewdirs) return go(k_mlp_fwd_bf16x3<true>, pts_per_ray, viewdirs, 4);
+    return go(k_mlp_fwd_bf16x3<false>, 1, nullptr, output_ch);
+}
+
+}  // extern "C"

@@ -97,8 +97,13 @@ class NeRF(nn.Module):
         self._packx4 = None
         self._x4_table = None
         self._flat_vec = None
-        # 'f32' (default; fp32 MFMA, the reference's precision) or 'bf16' (no-grad queries only: bf16 operands,
-        # fp32 accumulation, raw outputs within ~1e-2 of their scale; training always runs fp32)
+        self._pack16x3 = None
+        # What no-grad queries run (training always runs the fp32 matrix instruction):
+        #   'f32' (default)  fp32 accuracy; the kernel ops.F32_INFERENCE names (the split-operand kernel unless overridden)
+        #   'bf16x3'         fp32 accuracy on the bf16 matrix instruction: operands split exactly into three bf16 pieces,
+        #                    six piece products per product, fp32 sums (same error against fp64 as the fp32 instruction)
+        #   'f32_mfma'       the fp32 matrix instruction
+        #   'bf16'           reduced precision: bf16 operands, fp32 sums, raw outputs within ~1e-2 of their scale
         self.mlp_dtype = 'f32'
 
     # -- kernel plumbing ---------------------------------------------------------------------------
@@ -127,7 +132,7 @@ class NeRF(nn.Module):
             if not flat.is_cuda:
                 raise RuntimeError("NeRF parameters must live on a HIP device (call .to('cuda'))")
             self._flat_vec, self._pack_key = flat, key
-            self._pack = self._pack16 = self._packx4 = None
+            self._pack = self._pack16 = self._packx4 = self._pack16x3 = None
         return self._flat_vec
 
     def _packed(self, want_bwd: bool):
@@ -145,6 +150,12 @@ class NeRF(nn.Module):
         if self._pack16 is None:
             self._pack16 = ops.pack_weights_bf16(flat, self.use_viewdirs, self.output_ch)
         return self._pack16
+
+    def _packed_bf16x3(self):
+        flat = self._flat()
+        if self._pack16x3 is None:
+            self._pack16x3 = ops.pack_weights_bf16x3(flat, self.use_viewdirs, self.output_ch)
+        return self._pack16x3
 
     def _packed_x4_pair(self):
         """(forward stream, transposed stream) of the 16-point-tile kernels: one gather through a map built once."""

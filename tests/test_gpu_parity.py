@@ -327,18 +327,60 @@ def test_mlp_forward_ragged_sizes_and_peaky_weights(device):
             want = O.query_field(pts, vd, sd)
         scale = float(want.abs().max())
         close(raw, want, 3e-5, 3e-6 * max(1.0, scale), f"mlp {n}x{s}")
-        # the three fp32 routes to the same numbers: 16-point tiles (what no_grad queries run, checked above), the
-        # 32-point-tile entry without saving, and the training forward that saves activations
+        # the four fp32-accurate routes to the same numbers: the split-operand kernel (what no_grad queries run, checked
+        # above), the fp32 matrix instruction on 16-point and on 32-point tiles, and the training forward that saves
+        # activations
         from nerf_amd import ops
         flat_pts, dirs = pts.reshape(-1, 3).to(device), vd.to(device)
         with torch.no_grad():
             raw32 = ops.mlp_forward(flat_pts, dirs, m._packed(False)[0], True, 5, s)
             raw16 = ops.mlp_forward_x4(flat_pts, dirs, m._packed_x4(), True, 5, s)
+            raw3 = ops.mlp_forward_bf16x3(flat_pts, dirs, m._packed_bf16x3(), True, 5, s)
         close(raw32.reshape(n, s, 4), want, 3e-5, 3e-6 * max(1.0, scale), f"mlp 32-point tiles {n}x{s}")
-        close(raw16.reshape(n, s, 4), raw, 0, 0, f"mlp 16-point tiles {n}x{s} (same kernel as the query)")
+        close(raw16.reshape(n, s, 4), want, 3e-5, 3e-6 * max(1.0, scale), f"mlp 16-point tiles {n}x{s}")
+        close(raw3.reshape(n, s, 4), raw, 0, 0, f"mlp split-operand kernel {n}x{s} (same kernel as the query)")
         raw_train = qf(pts.to(device), vd.to(device), m)
         assert raw_train.requires_grad
         close(raw_train, want, 3e-5, 3e-6 * max(1.0, scale), f"mlp training forward {n}x{s}")
+
+
+def test_split_operand_kernel_is_as_accurate_as_the_fp32_matrix_instruction(device):
+    """The default no-grad kernel rebuilds every fp32 product from exact three-way bf16 splits (six piece products, fp32
+    sums).  Against an fp64 evaluation its error is that of the fp32 matrix-instruction kernel (within 1.5x, or below
+    1e-6 of the outputs' scale), with and without the view branch, on random and on peaky weights; and a model told to
+    use the fp32 matrix instruction (mlp_dtype = 'f32_mfma') renders within the usual summation-order distance."""
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import NeRF
+    rng = np.random.Generator(np.random.PCG64(77))
+    qf = _query_fn()
+    for use_vd, peak, n, s in ((True, 1.0, 300, 64), (True, 30.0, 130, 33), (False, 1.0, 257, 17)):
+        if use_vd:
+            sd = _peaky(O.random_state_dict(400 + n), peak)
+            m = _model(sd, device)
+        else:
+            sd = O.random_state_dict(401, use_viewdirs=False)
+            sd = {k: v for k, v in sd.items() if not k.startswith("views_linears")}
+            m = NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+            m.load_state_dict(sd, strict=False)
+            m = m.to(device)
+        pts = T(rng.uniform(-4, 4, size=(n, s, 3)).astype(np.float32))
+        vd = T(rng.normal(size=(n, 3)).astype(np.float32))
+        vd = vd / vd.norm(dim=-1, keepdim=True)
+        truth = O.query_field(pts.double(), vd.double() if use_vd else None, {k: v.double() for k, v in sd.items()})
+        flat, dirs = pts.reshape(-1, 3).to(device), vd.to(device) if use_vd else None
+        with torch.no_grad():
+            r3 = ops.mlp_forward_bf16x3(flat, dirs, m._packed_bf16x3(), use_vd, 5, s).cpu().double().reshape(truth.shape)
+            r32 = ops.mlp_forward_x4(flat, dirs, m._packed_x4(), use_vd, 5, s).cpu().double().reshape(truth.shape)
+            assert m.mlp_dtype == 'f32'
+            default = qf(pts.to(device), dirs, m)
+            m.mlp_dtype = 'f32_mfma'
+            forced = qf(pts.to(device), dirs, m)
+            m.mlp_dtype = 'f32'
+        scale = float(truth.abs().max())
+        e3, e32 = float((r3 - truth).abs().max()), float((r32 - truth).abs().max())
+        assert e3 <= max(1.5 * e32, 1e-6 * scale), (use_vd, peak, e3, e32, scale)
+        assert torch.equal(default.cpu().double(), r3) and torch.equal(forced.cpu().double(), r32)
+        close(default, forced.cpu(), 3e-5, 3e-6 * max(1.0, scale), "split-operand kernel vs fp32 matrix instruction")
 
 
 def _rng_inputs(n, sc, si, perturb, std):
