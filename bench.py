@@ -34,10 +34,13 @@ sys.path.insert(0, ROOT)
 FLOP_PER_POINT_FWD = 1186816          # 2 * 593,408 MAC: one NeRF.forward on one sample point
 FLOP_PER_POINT_TRAIN = 3489024        # forward + dW + dX
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X v_mfma_f32_32x32x2_f32 peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
+PEAK_BF16_MATRIX_TFLOPS = 2500.0      # MI355X dense bf16 matrix peak
+SPLIT_PRODUCTS = 6                    # bf16 matrix instructions the split-operand kernel issues per fp32-accurate product
 # HBM bytes per point of the inference kernel from rocprofv3 PMC passes (profiles/r1_pmc_mlp_fwd.txt):
 # (2 x FETCH_SIZE + WRITE_SIZE) / points = (2 x 36,774 KiB + 64,000 KiB) / 4,096,000 points per launch.
 # The algorithmic figure is 28 B/point (12 B position in, 16 B raw out) + 12 B per ray of view direction.
 PMC_HBM_BYTES_PER_POINT = 34.39
+PMC_HBM_BYTES_PER_POINT_X3 = None     # same counters for the split-operand kernel (None: not collected)
 
 
 def lego_camera(H, W):
@@ -312,25 +315,64 @@ def main():
     value = rays_per_step * args.steps * world / dt
 
     # dominant kernel: fused encode + MLP forward, timed per launch with events on the launch stream
-    mlp = [(n, s.elapsed_time(e) * 1e-3) for (name, n, s, e) in prof if name == "mlp_fwd"]
-    pts = sum(n for n, _ in mlp)
-    secs = sum(t for _, t in mlp)
-    achieved = pts * FLOP_PER_POINT_FWD / secs / 1e12 if secs > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd_x4<viewdirs> (fp32 MFMA 16x16x4, 16 points per wave, two waves per SIMD)", "achieved": round(achieved, 2),
-                "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
-                "traffic": round(PMC_HBM_BYTES_PER_POINT * pts / max(1, len(mlp))),
-                "traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of a separate rocprofv3 run, see profiles/",
-                "launches": len(mlp), "mean_launch_ms": round(1e3 * secs / max(1, len(mlp)), 3),
-                "flop_per_point": FLOP_PER_POINT_FWD, "mlp_share_of_step": round(secs / dt, 4)}
+    def mlp_roofline(records, kind, step_secs):
+        k = [(n, st.elapsed_time(en) * 1e-3) for (name, n, st, en) in records if name == ("mlp_fwd_bf16x3" if kind == "bf16x3" else "mlp_fwd")]
+        n_pts = sum(n for n, _ in k)
+        secs = sum(t for _, t in k)
+        achieved = n_pts * FLOP_PER_POINT_FWD / secs / 1e12 if secs > 0 else 0.0
+        if kind == "bf16x3":
+            # fp32-accurate products out of six bf16 matrix instructions each: the ceiling for the ALGORITHMIC (fp32) FLOP
+            # is a sixth of the dense bf16 peak; `executed` is what the matrix pipe actually ran
+            peak = PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS
+            r = {"bound": "mfma", "kernel": "k_mlp_fwd_bf16x3<viewdirs> (v_mfma_f32_16x16x32_bf16 on exact three-way bf16 splits, "
+                 "six piece products per fp32 product, fp32 accumulate; one wave per SIMD)", "achieved": round(achieved, 2),
+                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                 "peak_note": "dense bf16 matrix peak (2500 TFLOP/s) / 6 instructions per product; the fp32 matrix peak is 157.3",
+                 "executed_bf16_tflops": round(SPLIT_PRODUCTS * achieved, 1),
+                 "vs_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3),
+                 "traffic": (round(PMC_HBM_BYTES_PER_POINT_X3 * n_pts / max(1, len(k))) if PMC_HBM_BYTES_PER_POINT_X3 else None)}
+        else:
+            r = {"bound": "mfma", "kernel": "k_mlp_fwd_x4<viewdirs> (fp32 MFMA 16x16x4, 16 points per wave, two waves per SIMD)",
+                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": round(PMC_HBM_BYTES_PER_POINT * n_pts / max(1, len(k)))}
+        r.update({"traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of a separate rocprofv3 run, see profiles/",
+                  "launches": len(k), "mean_launch_ms": round(1e3 * secs / max(1, len(k)), 3),
+                  "flop_per_point": FLOP_PER_POINT_FWD, "mlp_share_of_step": round(secs / step_secs, 4)})
+        return r
+
+    default_kind = "bf16x3" if ops.F32_INFERENCE == "bf16x3" else "mfma32"
+    roofline = mlp_roofline(prof, default_kind, dt)
 
     out = {"metric": "rays/sec per GPU (train step + render) at 64+128 samples; 1/2/4/8 GPU scaling",
            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None,
+           "dtype": ("f32 (every product rebuilt exactly from three-way bf16 splits of both operands, fp32 accumulate: error "
+                     "against fp64 equal to the fp32 matrix instruction's)" if default_kind == "bf16x3" else "f32"),
+           "data": "synthetic",
            "config": {"workload": f"lego {H}x{W} render_only, N_samples=64, N_importance=128, chunk={chunk}, white_bkgd, "
                                   "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
                       "parallelism": f"ray/view-sharded x{world}, no collective"},
            "roofline": roofline, "hbm_kernels": hbm_kernels(prof)}
+
+    if default_kind == "bf16x3":
+        # the same render on the fp32 matrix instruction (mlp_dtype = 'f32_mfma'), with that kernel's own roofline
+        for m in models:
+            m.mlp_dtype = 'f32_mfma'
+        step(0)
+        ops.PROFILE = []
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        sync()
+        dt32 = time.perf_counter() - t0
+        prof32, ops.PROFILE = ops.PROFILE, None
+        for m in models:
+            m.mlp_dtype = 'f32'
+        out["render_f32_mfma"] = {"rays_per_s": round(rays_per_step * args.steps / dt32, 1), "ms_per_step": round(1e3 * dt32 / args.steps, 3),
+                                  "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "note": "per-GPU, this rank only",
+                                  "roofline": mlp_roofline(prof32, "mfma32", dt32)}
 
     if not args.no_bf16:
         # the bf16-operand / fp32-accumulate variant of the same render (reduced precision: reported, never `value`)

@@ -39,13 +39,18 @@ constexpr int X3_WG_PTS = X3_WAVES * WAVE_PTS; // 128 points per workgroup
 constexpr int TRIPLE_BYTES = 3 * 1024;
 constexpr int SLABT = 8;                       // triples per slab (every section of the stream is a multiple of 8)
 constexpr int SLAB3_BYTES = SLABT * TRIPLE_BYTES;
-constexpr int RING3_BYTES = 2 * SLAB3_BYTES;
+constexpr int RING_DEPTH = 3;                  // slabs in the LDS ring: slab n+2 is requested when slab n is opened
+constexpr int RING3_BYTES = RING_DEPTH * SLAB3_BYTES;
 constexpr int WAVE_BLOCKS3 = SLABT * 3 / X3_WAVES;   // 1 KiB blocks each wave fetches per slab
 
 __host__ __device__ inline int x3_stream_slabs(int use_viewdirs) { return bf16_stream_blocks(use_viewdirs) / SLABT; }
 __host__ __device__ inline int64_t x3_packed_bytes(int use_viewdirs) {
     return (int64_t)x3_stream_slabs(use_viewdirs) * SLAB3_BYTES + (int64_t)AUX16_FLOATS * 4;
 }
+
+// LDS behind the ring: the fp32 tables, then the split encodings (fragments per piece and wave)
+__host__ __device__ constexpr int aux_floats(int use_viewdirs) { return use_viewdirs ? AUX16_HEAD + 648 : AUX16_FLOATS; }
+__host__ __device__ constexpr int enc_frags(int use_viewdirs) { return (use_viewdirs ? 3 : 2) * NCT; }
 
 // x = hi + mid + lo, exactly (each difference of an fp32 and its bf16 rounding is an fp32)
 __host__ __device__ inline void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -62,16 +67,23 @@ struct Stream3 {
     int next, nslabs;
     __device__ __forceinline__ void fetch(int slab) {
         const char* src = g + (int64_t)slab * SLAB3_BYTES;
-        char* dst = mine + (slab & 1) * SLAB3_BYTES;
+        char* dst = mine + (slab % RING_DEPTH) * SLAB3_BYTES;
 #pragma unroll
         for (int b = 0; b < WAVE_BLOCKS3; ++b)
             glds16(reinterpret_cast<const float*>(src + b * 1024), reinterpret_cast<float*>(dst + b * 1024));
     }
+    // Opens slab `next`: its loads (issued two slabs ago) have landed -- those of slab next+1 may still be in flight,
+    // loads return in order -- and every wave is done with slab next-1, whose buffer the request for slab next+2 reuses.
     __device__ __forceinline__ const char* advance(int lane) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const char* cur = ring + (next & 1) * SLAB3_BYTES + lane * 16;
-        if (next + 1 < nslabs) fetch(next + 1);
+        static_assert(WAVE_BLOCKS3 == 6, "the wait below leaves one slab's loads of this wave in flight");
+        if (next + 1 < nslabs) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // a bare barrier: __syncthreads() would first wait for ALL of this wave's loads, the next slab's included.  The
+        // buffer requested below was last read a whole slab ago (reads run three triples ahead of their MFMAs), so no
+        // LDS read of it is still pending in any wave.
+        asm volatile("s_barrier" ::: "memory");
+        const char* cur = ring + (next % RING_DEPTH) * SLAB3_BYTES + lane * 16;
+        if (next + 2 < nslabs) fetch(next + 2);
         ++next;
         return cur;
     }
@@ -102,7 +114,7 @@ template <int NOUT, int NKS, int NHEAD, bool STORE, typename InFrag>
 __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const char*& cur, InFrag in_frag,
                                          bf16x8 (&Y)[3][NCT][8], const float* bias_lds, float lo, const float* head_lds,
                                          int head_stride, float (&head)[NCT][3]) {
-    constexpr int NB = NOUT * NKS, DEPTH = 3, NPIECE = 2 * NCT;
+    constexpr int NB = NOUT * NKS, DEPTH = 3, NPIECE = 4 * NCT;
     constexpr bool BIAS_INIT = NKS >= 7;
     constexpr int PPS = (NPIECE + (NKS < 8 ? NKS : 8) - 1) / (NKS < 8 ? NKS : 8);   // epilogue pieces per k-step
     bf16x8 abuf[DEPTH + 1][3];
@@ -110,34 +122,24 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
     const float* bp = bias_lds + 4 * g;
     const float* hp = head_lds + 4 * g;
 
-    auto load_bias = [&]<int TO>() {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + 16 * TO);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[TO & 1][ct] = bb;
-    };
-    auto piece = [&]<int TP, int K>() {           // K = 2 * column tile + register pair
-        constexpr int ct = K >> 1, pr = K & 1;
-        float v0 = acc[TP & 1][ct][2 * pr], v1 = acc[TP & 1][ct][2 * pr + 1];
-        if constexpr (!BIAS_INIT) {
-            const f32x2 bb = *reinterpret_cast<const f32x2*>(bp + 16 * TP + 2 * pr);
-            v0 += bb[0];
-            v1 += bb[1];
-        }
-        v0 = fmaxf(v0, lo);
-        v1 = fmaxf(v1, lo);
+    // the bias column of a tile is the C operand of its first MFMAs; it is read while the tile before is multiplying
+    f32x4 bnext = {0, 0, 0, 0};
+    auto load_bias = [&]<int TO>() { bnext = *reinterpret_cast<const f32x4*>(bp + 16 * TO); };
+    auto piece = [&]<int TP, int K>() {           // K = 4 * column tile + register: one value of the tile per piece
+        constexpr int ct = K >> 2, r = K & 3;
+        float v = acc[TP & 1][ct][r];
+        if constexpr (!BIAS_INIT) v += bp[16 * TP + r];
+        v = fmaxf(v, lo);
 #pragma unroll
         for (int k = 0; k < NHEAD; ++k) {
-            const f32x2 w = *reinterpret_cast<const f32x2*>(hp + k * head_stride + 16 * TP + 2 * pr);
-            head[ct][k] = fmaf(v1, w[1], fmaf(v0, w[0], head[ct][k]));
+            head[ct][k] = fmaf(v, hp[k * head_stride + 16 * TP + r], head[ct][k]);
             asm volatile("" : "+v"(head[ct][k]));   // keep the head sums here (see mlp_fwd_bf16.hip)
         }
         if constexpr (STORE) {
-            constexpr int f = TP >> 1, s0 = 4 * (TP & 1) + 2 * pr;
+            constexpr int f = TP >> 1, slot = 4 * (TP & 1) + r;
             __bf16 h, m, l;
-            split3(v0, h, m, l);
-            Y[0][ct][f][s0] = h; Y[1][ct][f][s0] = m; Y[2][ct][f][s0] = l;
-            split3(v1, h, m, l);
-            Y[0][ct][f][s0 + 1] = h; Y[1][ct][f][s0 + 1] = m; Y[2][ct][f][s0 + 1] = l;
+            split3(v, h, m, l);
+            Y[0][ct][f][slot] = h; Y[1][ct][f][slot] = m; Y[2][ct][f][slot] = l;
         }
     };
 
@@ -157,9 +159,8 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
                 const bf16x8 a = abuf[b % (DEPTH + 1)][pw];
                 static_for<NCT>([&]<int CT>() {
                     const bf16x8 x = in_frag.template operator()<CT, ks, px>();
-                    if constexpr (!BIAS_INIT && ks == 0 && P == 0) {
-                        const f32x4 zero = {0, 0, 0, 0};
-                        acc[to & 1][CT] = mfma16(a, x, zero);
+                    if constexpr (ks == 0 && P == 0) {   // (bnext stays zero in the layers that add the bias in the epilogue)
+                        acc[to & 1][CT] = mfma16(a, x, bnext);
                     } else {
                         acc[to & 1][CT] = mfma16(a, x, acc[to & 1][CT]);
                     }
@@ -187,16 +188,16 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
     float* aux = reinterpret_cast<float*>(smem3 + RING3_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     constexpr int UV = VIEWDIRS ? 1 : 0;
-    {
+    {   // (with the view branch only the first 648 head floats are in use: alpha row, three rgb rows, their biases)
         const float* gaux = reinterpret_cast<const float*>(packed + (int64_t)x3_stream_slabs(UV) * SLAB3_BYTES);
-        for (int i = tid * 4; i < AUX16_FLOATS; i += X3_THREADS * 4)
+        for (int i = tid * 4; i < aux_floats(UV); i += X3_THREADS * 4)
             *reinterpret_cast<f32x4*>(aux + i) = *reinterpret_cast<const f32x4*>(gaux + i);
     }
 
     // ---- encodings, split, parked in LDS: fragment (piece s, slot f) of this lane at ed[(s * NF + f) * 64],
     // f = 2 ct + k-step for the position, 2 NCT + ct for the direction
-    constexpr int NF = 3 * NCT;
-    bf16x8* ed = reinterpret_cast<bf16x8*>(smem3 + RING3_BYTES + AUX16_FLOATS * 4) + wave * (3 * NF * 64) + lane;
+    constexpr int NF = enc_frags(UV);
+    bf16x8* ed = reinterpret_cast<bf16x8*>(smem3 + RING3_BYTES + aux_floats(UV) * 4) + wave * (3 * NF * 64) + lane;
     auto park = [&](int f, const float* v) {
         bf16x8 h, m, l;
         split8(v, h, m, l);
@@ -248,6 +249,7 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
     st.nslabs = x3_stream_slabs(UV);
     __syncthreads();
     st.fetch(0);
+    st.fetch(1);
     const char* cur = nullptr;
 
     bf16x8 X[3][NCT][8], Y[3][NCT][8];
@@ -343,7 +345,8 @@ __global__ void __launch_bounds__(256) k_pack_bf16x3(int use_viewdirs, int outpu
     }
 }
 
-constexpr size_t X3_LDS_BYTES = RING3_BYTES + AUX16_FLOATS * sizeof(float) + X3_WAVES * 3 * 3 * NCT * 64 * 16;
+constexpr size_t x3_lds_bytes(int uv) { return RING3_BYTES + aux_floats(uv) * sizeof(float) + X3_WAVES * 3 * enc_frags(uv) * 64 * 16; }
+static_assert(x3_lds_bytes(1) <= 160 * 1024 && x3_lds_bytes(0) <= 160 * 1024, "LDS of one compute unit");
 
 }  // namespace
 
@@ -371,10 +374,10 @@ int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const 
     const int64_t blocks = (n_pts + X3_WG_PTS - 1) / X3_WG_PTS;
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_bf16x3: n_pts=%lld too large for one launch", (long long)n_pts);
     auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)X3_LDS_BYTES);
+        const size_t lds = x3_lds_bytes(use_viewdirs);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), X3_LDS_BYTES, as_stream(stream), n_pts, ppr, pts,
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), lds, as_stream(stream), n_pts, ppr, pts,
                            vd, och, reinterpret_cast<const char*>(packed), out);
         return launched("nerf_mlp_fwd_bf16x3");
     };
