@@ -40,7 +40,9 @@ SPLIT_PRODUCTS = 6                    # bf16 matrix instructions the split-opera
 # (2 x FETCH_SIZE + WRITE_SIZE) / points = (2 x 36,774 KiB + 64,000 KiB) / 4,096,000 points per launch.
 # The algorithmic figure is 28 B/point (12 B position in, 16 B raw out) + 12 B per ray of view direction.
 PMC_HBM_BYTES_PER_POINT = 34.39
-PMC_HBM_BYTES_PER_POINT_X3 = None     # same counters for the split-operand kernel (None: not collected)
+# same counters for the split-operand kernel: (2 x 321,248 KiB + 64,000 KiB) / 4,096,000 points: its 3.5 MB weight stream
+# no longer stays in L2 next to the point data (0.3 % of the 112 GB of weight reads per launch reach HBM)
+PMC_HBM_BYTES_PER_POINT_X3 = 176.62
 
 
 def lego_camera(H, W):
