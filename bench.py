@@ -349,8 +349,11 @@ def main():
            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
-           "dtype": ("f32 (every product rebuilt exactly from three-way bf16 splits of both operands, fp32 accumulate: error "
-                     "against fp64 equal to the fp32 matrix instruction's)" if default_kind == "bf16x3" else "f32"),
+           "dtype": "f32 via 3xbf16 splits" if default_kind == "bf16x3" else "f32",
+           "dtype_note": ("fp32 inputs, outputs and accuracy: every product is rebuilt exactly from three-way bf16 splits of both "
+                          "operands (six bf16 matrix instructions, fp32 accumulate); error against fp64 equal to the fp32 matrix "
+                          "instruction's, all parity tolerances unchanged; render_f32_mfma is the same render on the fp32 "
+                          "matrix instruction") if default_kind == "bf16x3" else "fp32 matrix instruction",
            "data": "synthetic",
            "config": {"workload": f"lego {H}x{W} render_only, N_samples=64, N_importance=128, chunk={chunk}, white_bkgd, "
                                   "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
