@@ -179,7 +179,8 @@ int nerf_pack_weights_bf16(int use_viewdirs, int output_ch, const float* params,
 int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                       int use_viewdirs, int output_ch, const void* packed_bf16, float* out, void* stream);
 
-/* fp32-accurate variant of nerf_mlp_fwd on the bf16 matrix instruction (same arguments and outputs, no-grad only):
+/* fp32-accurate variant of nerf_mlp_fwd on the bf16 matrix instruction (same arguments and outputs; `act` as in
+ * nerf_mlp_fwd_x4: NULL for inference, otherwise the saved activations and mask words nerf_mlp_bwd / _x4 read):
  * every fp32 operand is split exactly into three bf16 pieces and each product is rebuilt from its six largest
  * piece products in fp32 accumulators, which measures the same error against fp64 as the fp32 matrix instruction
  * (NeRF.forward, run_nerf_helpers.py:109-133, behind run_nerf.py:40-66).  packed_bf16x3:
@@ -187,7 +188,7 @@ int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const fl
 int64_t nerf_mlp_packed_bf16x3_bytes(int use_viewdirs);
 int nerf_pack_weights_bf16x3(int use_viewdirs, int output_ch, const float* params, void* packed_bf16x3, void* stream);
 int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
-                        int use_viewdirs, int output_ch, const void* packed_bf16x3, float* out, void* stream);
+                        int use_viewdirs, int output_ch, const void* packed_bf16x3, float* out, float* act, void* stream);
 
 /* Backward of nerf_mlp_fwd w.r.t. the parameters (inputs carry no gradient upstream:
  * run_nerf.py:467 detaches the samples).  d_out [n_pts,out_ch]; act from the forward;

@@ -111,10 +111,16 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& mid, 
 // One layer: NOUT row tiles (16 features each) x NKS k-steps (32 input features each) x NCT column tiles.
 // in_frag<CT, ks, S>() = piece S of the input fragment of column tile CT, k-step ks.  Y[S][CT][..] receives the pieces
 // of the output (STORE).  Everything else as layer16 of mlp_fwd_bf16.hip.
-template <int NOUT, int NKS, int NHEAD, bool STORE, typename InFrag>
+// SAVE (training): the unsplit fp32 values of a finished tile are also stored for the backward pass, one 16-byte store
+// per tile, column tile and lane into the blocked layout of mlp_layout.hpp (`srow[ct]` = the layer's first row group +
+// this lane's offset g * GROUP_FLOATS + 4 * (point in the 128-point tile): a lane's four values of tile t are the
+// four rows of row group 4 t + g); with MASK their ReLU mask bits are collected in mb[ct], dword t / 4, bit 8 (t % 4) + r
+// (the lane's share of the words the backward-data kernels read; see save_mask in the kernel).
+template <int NOUT, int NKS, int NHEAD, bool STORE, bool SAVE, bool MASK, typename InFrag>
 __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const char*& cur, InFrag in_frag,
                                          bf16x8 (&Y)[3][NCT][8], const float* bias_lds, float lo, const float* head_lds,
-                                         int head_stride, float (&head)[NCT][3]) {
+                                         int head_stride, float (&head)[NCT][3], float* (&srow)[NCT],
+                                         uint32_t (&mb)[NCT][4]) {
     constexpr int NB = NOUT * NKS, DEPTH = 3, NPIECE = 4 * NCT;
     constexpr bool BIAS_INIT = NKS >= 7;
     constexpr int PPS = (NPIECE + (NKS < 8 ? NKS : 8) - 1) / (NKS < 8 ? NKS : 8);   // epilogue pieces per k-step
@@ -125,6 +131,11 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
 
     // the bias column of a tile is the C operand of its first MFMAs; it is read while the tile before is multiplying
     f32x4 bnext = {0, 0, 0, 0};
+    f32x4 sv = {0, 0, 0, 0};                      // SAVE: the four values of (tile, column tile) being collected
+    if constexpr (MASK) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) mb[ct][0] = mb[ct][1] = mb[ct][2] = mb[ct][3] = 0u;
+    }
     auto load_bias = [&]<int TO>() { bnext = *reinterpret_cast<const f32x4*>(bp + 16 * TO); };
     auto piece = [&]<int TP, int K>() {           // K = 4 * column tile + register: one value of the tile per piece
         constexpr int ct = K >> 2, r = K & 3;
@@ -135,6 +146,14 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
         for (int k = 0; k < NHEAD; ++k) {
             head[ct][k] = fmaf(v, hp[k * head_stride + 16 * TP + r], head[ct][k]);
             asm volatile("" : "+v"(head[ct][k]));   // keep the head sums here (see mlp_fwd_bf16.hip)
+        }
+        if constexpr (MASK) {   // v >= 0 after the ReLU, so "positive" = "bits != 0"
+            const uint32_t one = __float_as_uint(v) < 1u ? __float_as_uint(v) : 1u;
+            mb[ct][TP >> 2] |= one << (8 * (TP & 3) + r);
+        }
+        if constexpr (SAVE) {
+            sv[r] = v;
+            if constexpr (r == 3) *reinterpret_cast<f32x4*>(srow[ct] + 4 * TP * GROUP_FLOATS) = sv;
         }
         if constexpr (STORE) {
             constexpr int f = TP >> 1, slot = 4 * (TP & 1) + r;
@@ -180,10 +199,10 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
     static_for<NPIECE>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
 }
 
-template <bool VIEWDIRS>
+template <bool VIEWDIRS, bool SAVE>
 __global__ void __launch_bounds__(X3_THREADS, 1)
 k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
-                 int output_ch, const char* __restrict__ packed, float* __restrict__ out) {
+                 int output_ch, const char* __restrict__ packed, float* __restrict__ out, float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     char* ring = smem3;
     float* aux = reinterpret_cast<float*>(smem3 + RING3_BYTES);
@@ -209,6 +228,9 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
     int64_t p[NCT];
     bool valid[NCT];
     const int c0 = enc16_first_pair(g);
+    // training: this workgroup's 128-point tile of the saved activations (mlp_layout.hpp)
+    static_assert(X3_WG_PTS == TILE_PTS, "one workgroup per tile of the saved activations");
+    float* const tile = SAVE ? act + (int64_t)blockIdx.x * act_rows(UV) * TILE_PTS : nullptr;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         p[ct] = (int64_t)blockIdx.x * X3_WG_PTS + wave * WAVE_PTS + ct * 16 + (lane & 15);
@@ -226,6 +248,14 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
         if (g == 3) { e[14] = x2; e[15] = 0.0f; }
         park(2 * ct + 0, e);
         park(2 * ct + 1, e + 8);
+        const int pw = wave * WAVE_PTS + ct * 16 + (lane & 15);   // point inside the tile
+        if constexpr (SAVE) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int f = enc16_pts_feature(q >> 3, g, q & 7), row = ACT_ENC_PTS + (f < 0 ? 63 : f);
+                tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid[ct] && f >= 0) ? e[q] : 0.0f;
+            }
+        }
         if (VIEWDIRS) {
             const int64_t ray = pl / pts_per_ray;
             const float v0 = viewdirs[ray * 3 + 0], v1 = viewdirs[ray * 3 + 1], v2 = viewdirs[ray * 3 + 2];
@@ -239,6 +269,15 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
             dd[6] = g == 0 ? v0 : (g == 1 ? v2 : 0.0f);
             dd[7] = g == 0 ? v1 : 0.0f;
             park(2 * NCT + ct, dd);
+            if constexpr (SAVE) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int f = enc16_dirs_feature(g, q);
+                    // the five slots without a feature zero the padding rows 27..31
+                    const int row = ACT_ENC_DIRS + (f >= 0 ? f : 27 + (g == 1 ? 0 : 2 * (g - 2) + 1 + (q - 6)));
+                    tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid[ct] && f >= 0) ? dd[q] : 0.0f;
+                }
+            }
         }
     }
 
@@ -272,18 +311,62 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
         if constexpr (ks < 8) return X[s][ct][ks]; else return ed[(s * NF + 2 * NCT + ct) * 64];
     };
 
-    layer_x3<16, 2, 0, true>(st, lane, g, cur, fromE, X, bias, 0.0f, hw, 0, sig);                    // L0
-    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromX, Y, bias + 1 * 256, 0.0f, hw, 0, sig);          // L1
-    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 2 * 256, 0.0f, hw, 0, sig);          // L2
-    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromX, Y, bias + 3 * 256, 0.0f, hw, 0, sig);          // L3
-    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 4 * 256, 0.0f, hw, 0, sig);          // L4
-    layer_x3<16, 10, 0, true>(st, lane, g, cur, fromXE, Y, bias + 5 * 256, 0.0f, hw, 0, sig);        // L5 (skip)
-    layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 6 * 256, 0.0f, hw, 0, sig);          // L6
+    // training: per column tile, this lane's slot in the tile (row group g, its point) and the mask-word writer
+    float* lane_rows[NCT];
+    uint32_t mb[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        lane_rows[ct] = SAVE ? tile + g * GROUP_FLOATS + (wave * WAVE_PTS + ct * 16 + (lane & 15)) * 4 : nullptr;
+        mb[ct][0] = mb[ct][1] = mb[ct][2] = mb[ct][3] = 0u;
+    }
+    // The backward-data kernels read one 16-byte word per masked layer and lane (point, half h): lanes (point, g = h) and
+    // (point, g = h + 2) of this kernel hold its bits between them, in nibbles that alternate (mlp_fwd_x4.hip, save_mask).
+    auto save_mask = [&](int m) {
+        if constexpr (SAVE) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                u32x4 w;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t mine = mb[ct][d] << (4 * (g >> 1));
+                    w[d] = mine | (uint32_t)__shfl_xor((int)mine, 32, 64);
+                }
+                const int pw = wave * WAVE_PTS + ct * 16 + (lane & 15);
+                if (g < 2) *reinterpret_cast<u32x4*>(tile + act_mask_offset(UV, m, pw >> 5, g * 32 + (pw & 31))) = w;
+            }
+        }
+    };
+    auto rows = [&](int row, float* (&dst)[NCT]) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) dst[ct] = lane_rows[ct] + (row / 4) * GROUP_FLOATS;
+    };
+    float* sr[NCT];
+#define X3_LAYER(NOUT, NKS, NHEAD, STORE, MASKED, IN, OUT, BIAS, LO, HEADW, HSTRIDE, HEAD, ROW)                        \
+    rows(ROW, sr);                                                                                                    \
+    layer_x3<NOUT, NKS, NHEAD, STORE, SAVE, SAVE && MASKED>(st, lane, g, cur, IN, OUT, BIAS, LO, HEADW, HSTRIDE, HEAD, sr, mb)
+
+    X3_LAYER(16, 2, 0, true, true, fromE, X, bias, 0.0f, hw, 0, sig, ACT_H0);                               // L0
+    save_mask(0);
+    X3_LAYER(16, 8, 0, true, true, fromX, Y, bias + 1 * 256, 0.0f, hw, 0, sig, ACT_H0 + 1 * 256);           // L1
+    save_mask(1);
+    X3_LAYER(16, 8, 0, true, true, fromY, X, bias + 2 * 256, 0.0f, hw, 0, sig, ACT_H0 + 2 * 256);           // L2
+    save_mask(2);
+    X3_LAYER(16, 8, 0, true, true, fromX, Y, bias + 3 * 256, 0.0f, hw, 0, sig, ACT_H0 + 3 * 256);           // L3
+    save_mask(3);
+    X3_LAYER(16, 8, 0, true, true, fromY, X, bias + 4 * 256, 0.0f, hw, 0, sig, ACT_H0 + 4 * 256);           // L4
+    save_mask(4);
+    X3_LAYER(16, 10, 0, true, true, fromXE, Y, bias + 5 * 256, 0.0f, hw, 0, sig, ACT_H0 + 5 * 256);         // L5 (skip)
+    save_mask(5);
+    X3_LAYER(16, 8, 0, true, true, fromY, X, bias + 6 * 256, 0.0f, hw, 0, sig, ACT_H0 + 6 * 256);           // L6
+    save_mask(6);
     auto over_groups = [](float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
     if constexpr (VIEWDIRS) {
-        layer_x3<16, 8, 1, true>(st, lane, g, cur, fromX, Y, bias + 7 * 256, 0.0f, hw, 0, sig);      // L7 + alpha head
-        layer_x3<16, 8, 0, true>(st, lane, g, cur, fromY, X, bias + 8 * 256, NOCLAMP, hw, 0, sig);   // feature
-        layer_x3<8, 9, 3, false>(st, lane, g, cur, fromXD, Y, bias + 9 * 256, 0.0f, hw + 256, 128, rgb);   // views + rgb heads
+        X3_LAYER(16, 8, 1, true, true, fromX, Y, bias + 7 * 256, 0.0f, hw, 0, sig, ACT_H0 + 7 * 256);       // L7 + alpha head
+        save_mask(7);
+        X3_LAYER(16, 8, 0, true, false, fromY, X, bias + 8 * 256, NOCLAMP, hw, 0, sig, ACT_FEAT);          // feature
+        X3_LAYER(8, 9, 3, false, true, fromXD, Y, bias + 9 * 256, 0.0f, hw + 256, 128, rgb, ACT_VIEWS);    // views + rgb heads
+        save_mask(8);
         const float* hb = hw + 256 + 384;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -295,7 +378,8 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
         }
     } else {
         // output_linear: rows 0..2 as fp32 head dot products inside the L7 epilogue, rows 3..7 from the pieces afterwards
-        layer_x3<16, 8, 3, true>(st, lane, g, cur, fromX, Y, bias + 7 * 256, 0.0f, hw, 256, sig);
+        X3_LAYER(16, 8, 3, true, true, fromX, Y, bias + 7 * 256, 0.0f, hw, 256, sig, ACT_H0 + 7 * 256);
+        save_mask(7);
         for (int ch = 0; ch < output_ch; ++ch) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -318,6 +402,7 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
             }
         }
     }
+#undef X3_LAYER
 }
 
 // flat parameters -> stream of triples + fp32 aux tables
@@ -364,7 +449,7 @@ int nerf_pack_weights_bf16x3(int use_viewdirs, int output_ch, const float* param
 }
 
 int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
-                        int output_ch, const void* packed, float* out, void* stream) {
+                        int output_ch, const void* packed, float* out, float* act, void* stream) {
     NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd_bf16x3: n_pts=%lld", (long long)n_pts);
     if (n_pts == 0) return 0;
     NERF_REQUIRE(pts && packed && out, "nerf_mlp_fwd_bf16x3: null pointer");
@@ -379,11 +464,12 @@ int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), lds, as_stream(stream), n_pts, ppr, pts,
-                           vd, och, reinterpret_cast<const char*>(packed), out);
+                           vd, och, reinterpret_cast<const char*>(packed), out, act);
         return launched("nerf_mlp_fwd_bf16x3");
     };
-    if (use_viewdirs) return go(k_mlp_fwd_bf16x3<true>, pts_per_ray, viewdirs, 4);
-    return go(k_mlp_fwd_bf16x3<false>, 1, nullptr, output_ch);
+    NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd_bf16x3: act must be 16-byte aligned");
+    if (use_viewdirs) return act ? go(k_mlp_fwd_bf16x3<true, true>, pts_per_ray, viewdirs, 4) : go(k_mlp_fwd_bf16x3<true, false>, pts_per_ray, viewdirs, 4);
+    return act ? go(k_mlp_fwd_bf16x3<false, true>, 1, nullptr, output_ch) : go(k_mlp_fwd_bf16x3<false, false>, 1, nullptr, output_ch);
 }
 
 }  // extern "C"

@@ -406,7 +406,7 @@ def pack_weights_bf16x3(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) 
 
 
 def mlp_forward_bf16x3(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed: torch.Tensor, use_viewdirs: bool,
-                       output_ch: int, pts_per_ray: int) -> torch.Tensor:
+                       output_ch: int, pts_per_ray: int, act: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32-accurate inference on the bf16 matrix instruction: three-way exact bf16 splits, six products, fp32 sums."""
     pts = _f32c(pts, "pts")
     n_pts = pts.numel() // 3
@@ -414,9 +414,9 @@ def mlp_forward_bf16x3(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], pack
     if use_viewdirs:
         viewdirs = _f32c(viewdirs, "viewdirs")
         assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
-    with torch.cuda.device(pts.device), _timed("mlp_fwd_bf16x3", n_pts):
+    with torch.cuda.device(pts.device), _timed("mlp_fwd_bf16x3" if act is None else "mlp_fwd_save", n_pts):
         check(lib.nerf_mlp_fwd_bf16x3(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
-                                      int(use_viewdirs), output_ch, packed.data_ptr(), out.data_ptr(), _stream()))
+                                      int(use_viewdirs), output_ch, packed.data_ptr(), out.data_ptr(), _ptr(act), _stream()))
     return out
 
 
@@ -485,6 +485,9 @@ def mlp_backward_x4(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, 
 F32_INFERENCE = os.environ.get("NERF_F32_INFERENCE", "bf16x3")
 assert F32_INFERENCE in ("bf16x3", "mfma32"), F32_INFERENCE
 
+# training forward (with saved activations) on the split-operand kernel (NERF_TRAIN_FWD_X3=0: the fp32 matrix instruction)
+TRAIN_FWD_X3 = os.environ.get("NERF_TRAIN_FWD_X3", "1") != "0"
+
 # backward-data stage on 16-point tiles (NERF_BWD_X4=0 selects the 32-point kernel, kept for A/B runs)
 BWD_X4 = os.environ.get("NERF_BWD_X4", "1") != "0"
 
@@ -501,7 +504,9 @@ class _FusedMLP(torch.autograd.Function):
             fwd, bwd, flat = model._packed(need_grad and not x4b)
         n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
-        if pts_per_ray > 0:   # raw positions: the 16-point-tile kernel (the 32-point one serves pre-encoded inputs)
+        if pts_per_ray > 0 and need_grad and TRAIN_FWD_X3:   # the split-operand kernel, saving activations
+            out = mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
+        elif pts_per_ray > 0:   # raw positions: the 16-point-tile kernel (the 32-point one serves pre-encoded inputs)
             out = mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
         else:
             out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
