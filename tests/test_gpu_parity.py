@@ -499,6 +499,7 @@ def _grad_close(got, want, what, rtol=2e-3, atol_frac=2e-5):
 def test_mlp_backward_matches_reference_and_oracle(device, monkeypatch, bwd_x4):
     from nerf_amd import ops
     monkeypatch.setattr(ops, "BWD_X4", bwd_x4)   # backward-data stage on 16-point or on 32-point tiles
+    monkeypatch.setattr(ops, "TRAIN_FWD_X3", bwd_x4)   # training forward: split-operand kernel or fp32 matrix instruction
     g = golden("mlp")
     qf = _query_fn()
     sd = O.random_state_dict(21)
@@ -549,6 +550,7 @@ def test_mlp_backward_sizes_and_no_view_branch(device, monkeypatch, bwd_x4):
     """Ragged point counts (tile padding, empty K slices) and the output_linear head, against oracle autograd."""
     from nerf_amd import ops
     monkeypatch.setattr(ops, "BWD_X4", bwd_x4)
+    monkeypatch.setattr(ops, "TRAIN_FWD_X3", bwd_x4)
     rng = np.random.Generator(np.random.PCG64(10))
     qf = _query_fn()
     for use_vd, n, s in ((True, 3, 5), (True, 70, 64), (False, 33, 8)):
