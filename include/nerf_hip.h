@@ -207,6 +207,16 @@ int nerf_pack_weights_bwd_x4(int use_viewdirs, int output_ch, const float* param
 int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                     const float* packed_x4, const float* packed_bwd_x4, float* scratch, float* d_params, void* stream);
 
+/* nerf_mlp_bwd with its first stage on the split-operand scheme (the mirror of nerf_mlp_fwd_bf16x3: dY tiles split
+ * exactly into three bf16 pieces, W^T as split triples, six piece products, fp32 sums), for the same autograd-derived
+ * backward of run_nerf_helpers.py:109-133.  Same d_out / act / scratch / d_params as nerf_mlp_bwd.  packed_bf16x3: the
+ * stream of nerf_pack_weights_bf16x3 (its fp32 tables are read); packed_bwd_bf16x3: nerf_mlp_packed_bwd_bf16x3_bytes()
+ * bytes built by nerf_pack_weights_bwd_bf16x3. */
+int64_t nerf_mlp_packed_bwd_bf16x3_bytes(int use_viewdirs);
+int nerf_pack_weights_bwd_bf16x3(int use_viewdirs, int output_ch, const float* params, void* packed_bwd_bf16x3, void* stream);
+int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                        const void* packed_bf16x3, const void* packed_bwd_bf16x3, float* scratch, float* d_params, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

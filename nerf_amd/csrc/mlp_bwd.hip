@@ -19,6 +19,12 @@
 #include "mlp_core.hpp"
 #include "mlp_x4.hpp"
 
+// stage 1 on the split-operand kernel (mlp_bwd_bf16x3.hip)
+namespace nerfx3 {
+int launch_bwd_data_x3(int64_t n_pts, int use_viewdirs, int output_ch, const float* d_out, const float* act,
+                       const void* packed_x3, const void* packed_bwd_x3, float* scratch, hipStream_t stream);
+}
+
 using namespace nerfhip;
 using namespace nerflayout;
 using namespace nerfmlp;
@@ -615,5 +621,30 @@ int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use
     return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
 }
 
+/* nerf_mlp_bwd with the backward-data stage on the split-operand kernel: packed_x3 (nerf_pack_weights_bf16x3, for the
+ * fp32 tables behind it) and packed_bwd_x3 (nerf_pack_weights_bwd_bf16x3) in place of the fp32 streams. */
+int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                        const void* packed_x3, const void* packed_bwd_x3, float* scratch, float* d_params, void* stream_) {
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd_bf16x3: n_pts=%lld", (long long)n_pts);
+    NERF_REQUIRE(d_params, "nerf_mlp_bwd_bf16x3: null d_params");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd_bf16x3: output_ch=%d not in 1..8", output_ch);
+    hipStream_t stream = as_stream(stream_);
+    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
+    if (n_pts == 0) {
+        hipError_t e0 = hipMemsetAsync(d_params, 0, po.total * sizeof(float), stream);
+        return e0 == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd_bf16x3: memset: %s", hipGetErrorString(e0));
+    }
+    NERF_REQUIRE(d_out && act && packed_x3 && packed_bwd_x3 && scratch, "nerf_mlp_bwd_bf16x3: null pointer");
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch) |
+                   reinterpret_cast<uintptr_t>(packed_x3) | reinterpret_cast<uintptr_t>(packed_bwd_x3)) & 15) == 0,
+                 "nerf_mlp_bwd_bf16x3: buffers must be 16-byte aligned");
+    const int64_t ldp = padded_points(n_pts);
+    NERF_REQUIRE(ldp / TILE_PTS <= 0x7fffffff, "nerf_mlp_bwd_bf16x3: n_pts=%lld too large for one call", (long long)n_pts);
+    const int64_t slab = slab_floats(use_viewdirs, output_ch);
+    float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
+    int rc = nerfx3::launch_bwd_data_x3(n_pts, use_viewdirs, output_ch, d_out, act, packed_x3, packed_bwd_x3, scratch, stream);
+    if (rc) return rc;
+    return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
+}
 
 }  // extern "C"

@@ -19,29 +19,16 @@
 #include "mlp_core.hpp"
 #include "mlp_tile16.hpp"
 #include "mlp_bf16_layout.hpp"
+#include "mlp_x3.hpp"
 
 using namespace nerfhip;
 using namespace nerflayout;
 using namespace nerfmlp;
 using namespace nerftile16;
 using namespace nerfbf16;
+using namespace nerfx3;
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int NCT = 2;                         // 16-point column tiles per wave
-constexpr int X3_THREADS = 256;                // four waves, one per SIMD
-constexpr int X3_WAVES = X3_THREADS / 64;
-constexpr int WAVE_PTS = 16 * NCT;
-constexpr int X3_WG_PTS = X3_WAVES * WAVE_PTS; // 128 points per workgroup
-constexpr int TRIPLE_BYTES = 3 * 1024;
-constexpr int SLABT = 8;                       // triples per slab (every section of the stream is a multiple of 8)
-constexpr int SLAB3_BYTES = SLABT * TRIPLE_BYTES;
-constexpr int RING_DEPTH = 3;                  // slabs in the LDS ring: slab n+2 is requested when slab n is opened
-constexpr int RING3_BYTES = RING_DEPTH * SLAB3_BYTES;
-constexpr int WAVE_BLOCKS3 = SLABT * 3 / X3_WAVES;   // 1 KiB blocks each wave fetches per slab
 
 __host__ __device__ inline int x3_stream_slabs(int use_viewdirs) { return bf16_stream_blocks(use_viewdirs) / SLABT; }
 __host__ __device__ inline int64_t x3_packed_bytes(int use_viewdirs) {
@@ -51,62 +38,6 @@ __host__ __device__ inline int64_t x3_packed_bytes(int use_viewdirs) {
 // LDS behind the ring: the fp32 tables, then the split encodings (fragments per piece and wave)
 __host__ __device__ constexpr int aux_floats(int use_viewdirs) { return use_viewdirs ? AUX16_HEAD + 648 : AUX16_FLOATS; }
 __host__ __device__ constexpr int enc_frags(int use_viewdirs) { return (use_viewdirs ? 3 : 2) * NCT; }
-
-// x = hi + mid + lo, exactly (each difference of an fp32 and its bf16 rounding is an fp32)
-__host__ __device__ inline void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
-    hi = (__bf16)x;
-    const float r1 = x - (float)hi;
-    mid = (__bf16)r1;
-    lo = (__bf16)(r1 - (float)mid);
-}
-
-struct Stream3 {
-    const char* g;   // this lane's source for block WAVE_BLOCKS3 * wave of slab 0
-    char* ring;
-    char* mine;
-    int next, nslabs;
-    __device__ __forceinline__ void fetch(int slab) {
-        const char* src = g + (int64_t)slab * SLAB3_BYTES;
-        char* dst = mine + (slab % RING_DEPTH) * SLAB3_BYTES;
-#pragma unroll
-        for (int b = 0; b < WAVE_BLOCKS3; ++b)
-            glds16(reinterpret_cast<const float*>(src + b * 1024), reinterpret_cast<float*>(dst + b * 1024));
-    }
-    // Opens slab `next`: its loads (issued two slabs ago) have landed -- those of slab next+1 may still be in flight,
-    // loads return in order -- and every wave is done with slab next-1, whose buffer the request for slab next+2 reuses.
-    // (One request per triple among the MFMAs, instead of six here, measured 3.6 % slower.)
-    __device__ __forceinline__ const char* advance(int lane) {
-        static_assert(WAVE_BLOCKS3 == 6, "the wait below leaves one slab's loads of this wave in flight");
-        if (next + 1 < nslabs) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // a bare barrier: __syncthreads() would first wait for ALL of this wave's loads, the next slab's included.  The
-        // buffer requested below was last read a whole slab ago (reads run three triples ahead of their MFMAs), so no
-        // LDS read of it is still pending in any wave.
-        asm volatile("s_barrier" ::: "memory");
-        const char* cur = ring + (next % RING_DEPTH) * SLAB3_BYTES + lane * 16;
-        if (next + 2 < nslabs) fetch(next + 2);
-        ++next;
-        return cur;
-    }
-};
-
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-
-// (weight piece, activation piece) of the six products, smallest first
-constexpr int PROD_W[6] = {1, 2, 0, 1, 0, 0};
-constexpr int PROD_X[6] = {1, 0, 2, 0, 1, 0};
-
-// eight fp32 values -> the three bf16 fragments of their pieces
-__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        __bf16 h, m, l;
-        split3(v[i], h, m, l);
-        hi[i] = h; mid[i] = m; lo[i] = l;
-    }
-}
 
 // One layer: NOUT row tiles (16 features each) x NKS k-steps (32 input features each) x NCT column tiles.
 // in_frag<CT, ks, S>() = piece S of the input fragment of column tile CT, k-step ks.  Y[S][CT][..] receives the pieces

@@ -485,6 +485,32 @@ def mlp_backward_x4(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, 
 F32_INFERENCE = os.environ.get("NERF_F32_INFERENCE", "bf16x3")
 assert F32_INFERENCE in ("bf16x3", "mfma32"), F32_INFERENCE
 
+def pack_weights_bwd_bf16x3(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    flat = _f32c(flat, "params")
+    assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
+    out = torch.empty(lib.nerf_mlp_packed_bwd_bf16x3_bytes(int(use_viewdirs)), dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_pack_weights_bwd_bf16x3(int(use_viewdirs), output_ch, flat.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x3: torch.Tensor,
+                        packed_bwd_x3: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    """mlp_backward with the backward-data stage on the split-operand kernel."""
+    d_out = _f32c(d_out, "d_out")
+    n_pts = d_out.shape[0]
+    scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
+    d_flat = torch.empty_like(flat)
+    with torch.cuda.device(d_out.device), _timed("mlp_bwd", n_pts):
+        check(lib.nerf_mlp_bwd_bf16x3(n_pts, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
+                                      packed_x3.data_ptr(), packed_bwd_x3.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(),
+                                      _stream()))
+    return d_flat
+
+
+# backward-data stage on the split-operand kernel (NERF_BWD_X3=0: the fp32 matrix instruction, see BWD_X4)
+BWD_X3 = os.environ.get("NERF_BWD_X3", "1") != "0"
+
 # training forward (with saved activations) on the split-operand kernel (NERF_TRAIN_FWD_X3=0: the fp32 matrix instruction)
 TRAIN_FWD_X3 = os.environ.get("NERF_TRAIN_FWD_X3", "1") != "0"
 
@@ -497,11 +523,12 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, viewdirs, model, pts_per_ray, need_grad, *params):
-        x4b = need_grad and BWD_X4
+        x3b = need_grad and BWD_X3
+        x4b = need_grad and BWD_X4 and not x3b
         flat = model._flat()
         fwd = bwd = None
-        if pts_per_ray == 0 or (need_grad and not x4b):
-            fwd, bwd, flat = model._packed(need_grad and not x4b)
+        if pts_per_ray == 0 or (need_grad and not (x4b or x3b)):
+            fwd, bwd, flat = model._packed(need_grad and not (x4b or x3b))
         n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
         if pts_per_ray > 0 and need_grad and TRAIN_FWD_X3:   # the split-operand kernel, saving activations
@@ -511,10 +538,12 @@ class _FusedMLP(torch.autograd.Function):
         else:
             out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
         if need_grad:
-            if x4b:   # the streams the 16-point-tile backward reads, in the slots of the 32-point ones
+            if x3b:   # the streams the backward in use reads, in the slots of the 32-point ones
+                fwd, bwd = model._packed_bf16x3(), model._packed_bwd_bf16x3()
+            elif x4b:
                 fwd, bwd = model._packed_x4(), model._packed_bwd_x4()
             ctx.save_for_backward(act, fwd, bwd, flat)
-            ctx.x4b = x4b
+            ctx.x4b, ctx.x3b = x4b, x3b
             ctx.model = model
             ctx.pts_per_ray = pts_per_ray
         return out
@@ -523,7 +552,9 @@ class _FusedMLP(torch.autograd.Function):
     def backward(ctx, d_out):
         act, fwd, bwd, flat = ctx.saved_tensors
         model = ctx.model
-        if ctx.x4b:
+        if ctx.x3b:
+            d_flat = mlp_backward_bf16x3(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
+        elif ctx.x4b:
             d_flat = mlp_backward_x4(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
         else:
             d_flat = mlp_backward(d_out, act, flat, bwd, fwd, model.use_viewdirs, model.output_ch, ctx.pts_per_ray)

@@ -98,6 +98,7 @@ class NeRF(nn.Module):
         self._x4_table = None
         self._flat_vec = None
         self._pack16x3 = None
+        self._pack16x3b = None
         # What no-grad queries run (training always runs the fp32 matrix instruction):
         #   'f32' (default)  fp32 accuracy; the kernel ops.F32_INFERENCE names (the split-operand kernel unless overridden)
         #   'bf16x3'         fp32 accuracy on the bf16 matrix instruction: operands split exactly into three bf16 pieces,
@@ -132,7 +133,7 @@ class NeRF(nn.Module):
             if not flat.is_cuda:
                 raise RuntimeError("NeRF parameters must live on a HIP device (call .to('cuda'))")
             self._flat_vec, self._pack_key = flat, key
-            self._pack = self._pack16 = self._packx4 = self._pack16x3 = None
+            self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = None
         return self._flat_vec
 
     def _packed(self, want_bwd: bool):
@@ -156,6 +157,12 @@ class NeRF(nn.Module):
         if self._pack16x3 is None:
             self._pack16x3 = ops.pack_weights_bf16x3(flat, self.use_viewdirs, self.output_ch)
         return self._pack16x3
+
+    def _packed_bwd_bf16x3(self):
+        flat = self._flat()
+        if self._pack16x3b is None:
+            self._pack16x3b = ops.pack_weights_bwd_bf16x3(flat, self.use_viewdirs, self.output_ch)
+        return self._pack16x3b
 
     def _packed_x4_pair(self):
         """(forward stream, transposed stream) of the 16-point-tile kernels: one gather through a map built once."""

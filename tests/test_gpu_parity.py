@@ -495,11 +495,14 @@ def _grad_close(got, want, what, rtol=2e-3, atol_frac=2e-5):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_frac * scale, err_msg=what)
 
 
-@pytest.mark.parametrize("bwd_x4", [True, False], ids=["bwd16", "bwd32"])
+@pytest.mark.parametrize("bwd_x4", ["x3", True, False], ids=["split", "bwd16", "bwd32"])
 def test_mlp_backward_matches_reference_and_oracle(device, monkeypatch, bwd_x4):
     from nerf_amd import ops
-    monkeypatch.setattr(ops, "BWD_X4", bwd_x4)   # backward-data stage on 16-point or on 32-point tiles
-    monkeypatch.setattr(ops, "TRAIN_FWD_X3", bwd_x4)   # training forward: split-operand kernel or fp32 matrix instruction
+    # "split": forward and backward-data on the split-operand kernels (the default); otherwise the fp32 matrix
+    # instruction: split-operand forward + backward-data on 16-point tiles, or fp32 forward + 32-point backward-data
+    monkeypatch.setattr(ops, "BWD_X3", bwd_x4 == "x3")
+    monkeypatch.setattr(ops, "BWD_X4", bool(bwd_x4))
+    monkeypatch.setattr(ops, "TRAIN_FWD_X3", bool(bwd_x4))
     g = golden("mlp")
     qf = _query_fn()
     sd = O.random_state_dict(21)
@@ -545,12 +548,13 @@ def _relu_margin(sd, pts, vd, use_vd):
     return margin.reshape(pts.shape[:-1])
 
 
-@pytest.mark.parametrize("bwd_x4", [True, False], ids=["bwd16", "bwd32"])
+@pytest.mark.parametrize("bwd_x4", ["x3", True, False], ids=["split", "bwd16", "bwd32"])
 def test_mlp_backward_sizes_and_no_view_branch(device, monkeypatch, bwd_x4):
     """Ragged point counts (tile padding, empty K slices) and the output_linear head, against oracle autograd."""
     from nerf_amd import ops
-    monkeypatch.setattr(ops, "BWD_X4", bwd_x4)
-    monkeypatch.setattr(ops, "TRAIN_FWD_X3", bwd_x4)
+    monkeypatch.setattr(ops, "BWD_X3", bwd_x4 == "x3")
+    monkeypatch.setattr(ops, "BWD_X4", bool(bwd_x4))
+    monkeypatch.setattr(ops, "TRAIN_FWD_X3", bool(bwd_x4))
     rng = np.random.Generator(np.random.PCG64(10))
     qf = _query_fn()
     for use_vd, n, s in ((True, 3, 5), (True, 70, 64), (False, 33, 8)):

@@ -35,6 +35,9 @@ for m, uv in ((models[0], True), (m2, False)):
         d_out = torch.randn(out.shape, device=dev, generator=g)
         a = ops.mlp_backward(d_out, act, flat, bwd, fwd, uv, 5, S)
         b = ops.mlp_backward_x4(d_out, act, flat, m._packed_x4(), m._packed_bwd_x4(), uv, 5)
+        c = ops.mlp_backward_bf16x3(d_out, act, flat, m._packed_bf16x3(), m._packed_bwd_bf16x3(), uv, 5)
+        tc = timed(lambda: ops.mlp_backward_bf16x3(d_out, act, flat, m._packed_bf16x3(), m._packed_bwd_bf16x3(), uv, 5))
+        print(f"   split-operand backward: max diff vs 32-pt {(a - c).abs().max().item():.3e}, finite={bool(torch.isfinite(c).all())}, {tc:.3f} ms", flush=True)
         d = (a - b).abs()
         rel = (d / (a.abs() + 1e-3 * a.abs().max())).max().item()
         ta = timed(lambda: ops.mlp_backward(d_out, act, flat, bwd, fwd, uv, 5, S))
