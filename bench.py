@@ -1,6 +1,10 @@
 """Benchmark of the render path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment the process starts N ranks of itself under
+torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) before it touches a GPU, relays rank 0's JSON line
+and exits with the launcher's status; under torch.distributed.run it is one of those ranks.
 
 One step = one pass of the hot path over one batch of synthetic input: a no-grad render of one full
 800x800 lego-shaped view (640,000 rays, 64 coarse + 128 fine samples, white background, view
@@ -36,13 +40,18 @@ FLOP_PER_POINT_TRAIN = 3489024        # forward + dW + dX
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X v_mfma_f32_32x32x2_f32 peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 PEAK_BF16_MATRIX_TFLOPS = 2500.0      # MI355X dense bf16 matrix peak
 SPLIT_PRODUCTS = 6                    # bf16 matrix instructions the split-operand kernel issues per fp32-accurate product
-# HBM bytes per point of the inference kernel from rocprofv3 PMC passes (profiles/r1_pmc_mlp_fwd.txt):
-# (2 x FETCH_SIZE + WRITE_SIZE) / points = (2 x 36,774 KiB + 64,000 KiB) / 4,096,000 points per launch.
-# The algorithmic figure is 28 B/point (12 B position in, 16 B raw out) + 12 B per ray of view direction.
-PMC_HBM_BYTES_PER_POINT = 34.39
-# same counters for the split-operand kernel: (2 x 321,248 KiB + 64,000 KiB) / 4,096,000 points: its 3.5 MB weight stream
-# no longer stays in L2 next to the point data (0.3 % of the 112 GB of weight reads per launch reach HBM)
-PMC_HBM_BYTES_PER_POINT_X3 = 176.62
+
+
+def pmc_traffic():
+    """HBM bytes per sample point of the MLP kernels, from rocprofv3 PMC passes of this command (2 x FETCH_SIZE +
+    WRITE_SIZE, the gfx950 correction for wide reads applied), as profiles/pmc_traffic.json records them together with
+    the files the figures come from.  The algorithmic figure is 28 B/point (12 B position in, 16 B raw out) + 12 B per
+    ray of view direction."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh)
+    except OSError:
+        return {}
 
 
 def lego_camera(H, W):
@@ -153,6 +162,27 @@ def hbm_kernels(prof):
                 "frac_of_hbm_peak": round(b / t / 1e9 / HBM_PEAK_GBS, 4)} for k, (b, t, c) in agg.items() if t > 0}
 
 
+# algorithmic FLOP per sample point of the three MLP kernels of a train step, and the matrix instruction each runs on
+# (the split-operand kernels issue six bf16 matrix instructions per fp32-accurate product)
+TRAIN_KERNEL_FLOP = {"mlp_fwd_save": 1186816, "mlp_bwd_data": 1115392, "mlp_bwd_dw": 1186816, "mlp_bwd": 2302208}
+
+
+def train_kernel_rooflines(prof):
+    """Per MLP kernel of the train step: algorithmic TFLOP/s from HIP events around each launch, against a sixth of the
+    dense bf16 matrix peak (what six split products per fp32 product allow)."""
+    out = {}
+    for name, flop_pt in TRAIN_KERNEL_FLOP.items():
+        k = [(n, s.elapsed_time(e) * 1e-3) for (nm, n, s, e) in prof if nm == name]
+        secs = sum(t for _, t in k)
+        if secs <= 0:
+            continue
+        tf = sum(n for n, _ in k) * flop_pt / secs / 1e12
+        out[name] = {"launches": len(k), "ms_total": round(1e3 * secs, 3), "tflops_algorithmic": round(tf, 1),
+                     "executed_bf16_tflops": round(SPLIT_PRODUCTS * tf, 1), "peak": round(PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS, 1),
+                     "frac": round(tf / (PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS), 4)}
+    return out
+
+
 def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=False, scene="lego"):
     """The upstream optimisation step (run_nerf.py:826-883, no_batching mode) on synthetic targets: rays of one
     400x400 view, n_rand random pixels, render with jitter, two MSE terms, backward, (all-reduce,) Adam, lr decay.
@@ -202,15 +232,22 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
         opt.zero_grad()
         loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
         loss.backward()
-        if world > 1:
+        if world > 1:   # one flat bucket, one all_reduce; bracketed by events on the stream the collective is ordered on
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
             parallel.allreduce_gradients(params)
+            ev[1].record()
+            if timing[0]:
+                ar_events.append(ev)
         opt.step()
         for g in opt.param_groups:
             g['lr'] = 5e-4 * (0.1 ** (i / (500 * 1000)))
         return loss
 
+    ar_events, timing = [], [False]
     for i in range(warmup):
         one(i)
+    timing[0] = True
     ops.PROFILE = None if graphed else []     # events recorded inside a graph cannot be timed
     if world > 1:
         torch.distributed.barrier()
@@ -231,18 +268,65 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
         for p, s0 in zip(params, saved):
             p.copy_(s0)
     for m in models:
-        m._pack_key = None
+        m.invalidate_packs()
     if graphed:
         return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
                 "n_rand_per_gpu": n_rand, "steps": steps, "final_loss": float(loss.detach()),
                 "note": "the same step replayed from two HIP graphs (render+loss+backward | Adam)"}
-    kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in ("mlp_fwd_save", "mlp_bwd"))
+    kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in TRAIN_KERNEL_FLOP)
     flop = n_rand * pts_per_ray * FLOP_PER_POINT_TRAIN * steps
-    return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "n_rand_per_gpu": n_rand,
-            "points_per_ray": pts_per_ray, "steps": steps, "final_loss": float(loss.detach()), "mlp_kernels_share_of_step": round(kern / dt, 4),
-            "mlp_tflops_algorithmic": round(flop / kern / 1e12, 2) if kern > 0 else None,
-            "frac_of_fp32_matrix_peak": round(flop / kern / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if kern > 0 else None,
-            "hbm_kernels": hbm_kernels(prof)}
+    res = {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "n_rand_per_gpu": n_rand,
+           "points_per_ray": pts_per_ray, "steps": steps, "final_loss": float(loss.detach()), "mlp_kernels_share_of_step": round(kern / dt, 4),
+           "mlp_tflops_algorithmic": round(flop / kern / 1e12, 2) if kern > 0 else None,
+           "kernels": train_kernel_rooflines(prof), "hbm_kernels": hbm_kernels(prof)}
+    if ar_events:
+        ar = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+        res["allreduce"] = {"ms_per_step": round(ar, 4), "share_of_step": round(ar * 1e-3 * steps / dt, 5),
+                            "bytes": 4 * sum(p.numel() for p in params), "backend": torch.distributed.get_backend(),
+                            "what": "flatten + one all_reduce(SUM) of both networks' gradients + scale + copy back, HIP events"}
+    return res
+
+
+def launch_ranks(n_gpus, argv, script=None):
+    """Start n_gpus ranks of this file under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and
+    relay rank 0's JSON line.  Runs before anything in this process has touched a GPU: the ranks are fresh child
+    processes, nothing is re-executed in place.  -> the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:            # rank 0 prints exactly one JSON object; anything else goes to stderr as it comes
+        text = out.strip()
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        elif text:
+            print(text, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def main():
@@ -254,7 +338,11 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=16384, help="rays in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-bf16", action="store_true")
+    ap.add_argument("--no-stress", action="store_true", help="skip the 256+512-sample sharded view of a multi-rank run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     if os.environ.get("BENCH_VERBOSE"):   # where a hung multi-rank run is stuck: stacks of all threads after N seconds
         import faulthandler
@@ -263,8 +351,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     # rehearsal aids for a one-GPU box: BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and BENCH_DIST_BACKEND=gloo
     # replaces RCCL (which refuses two ranks on one device); the driver's runs set neither
     if os.environ.get("BENCH_SINGLE_DEVICE"):
@@ -299,6 +386,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(secs):
+        if world > 1:
+            t = torch.tensor([secs], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            secs = float(t.item())
+        return secs
+
     for i in range(args.warmup):
         step(i)
     ops.PROFILE = []
@@ -310,12 +404,10 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
     rays_per_step = H * W
     value = rays_per_step * args.steps * world / dt
+    traffic = pmc_traffic()
 
     # dominant kernel: fused encode + MLP forward, timed per launch with events on the launch stream
     def mlp_roofline(records, kind, step_secs):
@@ -323,22 +415,26 @@ def main():
         n_pts = sum(n for n, _ in k)
         secs = sum(t for _, t in k)
         achieved = n_pts * FLOP_PER_POINT_FWD / secs / 1e12 if secs > 0 else 0.0
+        pmc = traffic.get("k_mlp_fwd_bf16x3" if kind == "bf16x3" else "k_mlp_fwd_x4", {})
+        per_point = pmc.get("hbm_bytes_per_point")
         if kind == "bf16x3":
             # fp32-accurate products out of six bf16 matrix instructions each: the ceiling for the ALGORITHMIC (fp32) FLOP
             # is a sixth of the dense bf16 peak; `executed` is what the matrix pipe actually ran
             peak = PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS
             r = {"bound": "mfma", "kernel": "k_mlp_fwd_bf16x3<viewdirs> (v_mfma_f32_16x16x32_bf16 on exact three-way bf16 splits, "
-                 "six piece products per fp32 product, fp32 accumulate; one wave per SIMD)", "achieved": round(achieved, 2),
+                 "six piece products per fp32 product, fp32 accumulate)", "achieved": round(achieved, 2),
                  "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                  "peak_note": "dense bf16 matrix peak (2500 TFLOP/s) / 6 instructions per product; the fp32 matrix peak is 157.3",
                  "executed_bf16_tflops": round(SPLIT_PRODUCTS * achieved, 1),
-                 "vs_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3),
-                 "traffic": (round(PMC_HBM_BYTES_PER_POINT_X3 * n_pts / max(1, len(k))) if PMC_HBM_BYTES_PER_POINT_X3 else None)}
+                 "vs_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3)}
         else:
             r = {"bound": "mfma", "kernel": "k_mlp_fwd_x4<viewdirs> (fp32 MFMA 16x16x4, 16 points per wave, two waves per SIMD)",
                  "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": round(PMC_HBM_BYTES_PER_POINT * n_pts / max(1, len(k)))}
-        r.update({"traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of a separate rocprofv3 run, see profiles/",
+                 "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4)}
+        r.update({"traffic": round(per_point * n_pts / max(1, len(k))) if per_point else None,
+                  "traffic_unit": "HBM bytes per launch = PMC bytes per point (2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 "
+                                  "passes, profiles/pmc_traffic.json) x points per launch of this run",
+                  "traffic_source": pmc.get("source"),
                   "launches": len(k), "mean_launch_ms": round(1e3 * secs / max(1, len(k)), 3),
                   "flop_per_point": FLOP_PER_POINT_FWD, "mlp_share_of_step": round(secs / step_secs, 4)})
         return r
@@ -350,8 +446,10 @@ def main():
            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
+           "value_note": "whole-job aggregate over all ranks (the contract's `value`); value_per_gpu is the metric's per-GPU figure",
+           "value_per_gpu": round(value / world, 1),
            "dtype": "f32 via 3xbf16 splits" if default_kind == "bf16x3" else "f32",
-           "dtype_note": ("fp32 inputs, outputs and accuracy: every product is rebuilt exactly from three-way bf16 splits of both "
+           "dtype_note": ("fp32 inputs, outputs and accuracy: every product is rebuilt from exact three-way bf16 splits of both "
                           "operands (six bf16 matrix instructions, fp32 accumulate); error against fp64 equal to the fp32 matrix "
                           "instruction's, all parity tolerances unchanged; render_f32_mfma is the same render on the fp32 "
                           "matrix instruction") if default_kind == "bf16x3" else "fp32 matrix instruction",
@@ -360,11 +458,13 @@ def main():
                                   "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
                       "parallelism": f"ray/view-sharded x{world}, no collective"},
            "roofline": roofline, "hbm_kernels": hbm_kernels(prof)}
+    if world > 1:
+        out["world_seen_by_backend"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                        "devices_visible": torch.cuda.device_count()}
 
-    if default_kind == "bf16x3":
-        # the same render on the fp32 matrix instruction (mlp_dtype = 'f32_mfma'), with that kernel's own roofline
+    def timed_variant(dtype_name):
         for m in models:
-            m.mlp_dtype = 'f32_mfma'
+            m.mlp_dtype = dtype_name
         step(0)
         ops.PROFILE = []
         sync()
@@ -372,29 +472,22 @@ def main():
         for i in range(args.steps):
             step(args.warmup + i)
         sync()
-        dt32 = time.perf_counter() - t0
-        prof32, ops.PROFILE = ops.PROFILE, None
+        secs = time.perf_counter() - t0
+        records, ops.PROFILE = ops.PROFILE, None
         for m in models:
             m.mlp_dtype = 'f32'
+        return secs, records
+
+    if default_kind == "bf16x3":
+        # the same render on the fp32 matrix instruction (mlp_dtype = 'f32_mfma'), with that kernel's own roofline
+        dt32, prof32 = timed_variant('f32_mfma')
         out["render_f32_mfma"] = {"rays_per_s": round(rays_per_step * args.steps / dt32, 1), "ms_per_step": round(1e3 * dt32 / args.steps, 3),
                                   "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "note": "per-GPU, this rank only",
                                   "roofline": mlp_roofline(prof32, "mfma32", dt32)}
 
     if not args.no_bf16:
         # the bf16-operand / fp32-accumulate variant of the same render (reduced precision: reported, never `value`)
-        for m in models:
-            m.mlp_dtype = 'bf16'
-        step(0)
-        ops.PROFILE = []
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        sync()
-        dt16 = time.perf_counter() - t0
-        prof16, ops.PROFILE = ops.PROFILE, None
-        for m in models:
-            m.mlp_dtype = 'f32'
+        dt16, prof16 = timed_variant('bf16')
         k16 = [(n, s.elapsed_time(e) * 1e-3) for (name, n, s, e) in prof16 if name == "mlp_fwd_bf16"]
         s16 = sum(t for _, t in k16)
         out["render_bf16"] = {"rays_per_s": round(rays_per_step * args.steps / dt16, 1), "ms_per_step": round(1e3 * dt16 / args.steps, 3),
@@ -403,39 +496,41 @@ def main():
                               "note": "per-GPU, this rank only; tolerance vs fp32: raw within 2e-2 of scale, rgb within 1e-2"}
 
     if world > 1 or os.environ.get("BENCH_FORCE_SHARDED"):
-        # one view cut into world_size ray slices, reassembled with one all_gather (strong scaling of a single frame);
-        # reported next to `value`, never instead of it
-        try:
-            from nerf_amd import parallel
-            from nerf_amd.run_nerf_helpers import get_rays
+        # ONE view cut into world_size contiguous ray slices, reassembled with one all_gather of 20 bytes per ray (strong
+        # scaling of a single frame), at the benchmark's 64+128 samples and at the stress shape (256 coarse + 512 fine
+        # samples, chunk 65536); reported next to `value`, never instead of it
+        from nerf_amd import parallel
+        from nerf_amd.run_nerf_helpers import get_rays
+        shared_poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(n_views)]   # the same view on every rank
 
-            shared_poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(n_views)]   # the same view on every rank
-
+        def sharded(kw, chunk_rays, n_timed):
             def frame(i):
                 with torch.no_grad():
-                    o, d = get_rays(H, W, K, shared_poses[i])
-                    return parallel.render_sharded(H, W, K, chunk, (o, d), **kwargs)
+                    o, d = get_rays(H, W, K, shared_poses[i % n_views])
+                    return parallel.render_sharded(H, W, K, chunk_rays, (o, d), **kw)
             frame(0)
             sync()
             t0 = time.perf_counter()
-            for i in range(args.steps):
-                full = frame(i % n_views)
+            for i in range(n_timed):
+                full = frame(i)
             sync()
-            dts = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([dts], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dts = float(t.item())
-            out["render_one_view_sharded"] = {"rays_per_s": round(rays_per_step * args.steps / dts, 1),
-                                              "ms_per_view": round(1e3 * dts / args.steps, 3), "ranks": world,
-                                              "gathered_bytes_per_view": rays_per_step * 20,
-                                              "rgb_checksum": float(full[0].double().sum().item())}
-        except Exception as exc:  # the headline number must survive a failure of this extra
-            out["render_one_view_sharded"] = {"error": repr(exc)}
+            secs = max_over_ranks(time.perf_counter() - t0)
+            return {"rays_per_s": round(rays_per_step * n_timed / secs, 1), "ms_per_view": round(1e3 * secs / n_timed, 3),
+                    "views": n_timed, "ranks": world, "rays_per_rank": -(-rays_per_step // world), "chunk": chunk_rays,
+                    "samples": f"{kw['N_samples']}+{kw['N_importance']}", "gathered_bytes_per_view": rays_per_step * 20,
+                    "rgb_checksum": float(full[0].double().sum().item())}
+        legs = [("render_one_view_sharded", kwargs, chunk, args.steps)]
+        if not args.no_stress:
+            legs.append(("render_one_view_sharded_stress", dict(kwargs, N_samples=256, N_importance=512), 1024 * 64, 1))
+        for key, kw, chunk_rays, n_timed in legs:
+            try:
+                out[key] = sharded(kw, chunk_rays, n_timed)
+            except Exception as exc:  # the headline number must survive a failure of this extra
+                out[key] = {"error": repr(exc)}
 
     if not args.no_train:
         # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)
-        for key, n_rand, k, w, seed in (("train_8192", 8192, 4, 2, 4321), ("train", 1024, 20, 5, 1234)):
+        for key, n_rand, k, w, seed in (("train_8192", 8192, 10, 2, 4321), ("train", 1024, 20, 5, 1234)):
             try:
                 out[key] = time_train(models, kwargs, dev, world, n_rand, k, w, seed=seed + rank)
             except Exception as exc:  # the headline number must survive a failure of an extra
@@ -457,15 +552,16 @@ def main():
             got = last[0].reshape(-1, 3)[pick.to(dev)].cpu()
             err = float((got - cpu_out["rgb_map"]).abs().max())
             out["cpu_baseline"] = {"value": round(cpu_rps, 1), "unit": "rays/s", "cores": torch.get_num_threads(),
+                                   "cpu_model": cpu_model(),
                                    "kind": "port", "sample": f"{args.cpu_rays} random rays of the last benchmark view, "
                                    "same weights, PyTorch-CPU oracle", "host_cpus": os.cpu_count(),
                                    "max_abs_rgb_diff_vs_gpu": err, "speedup_per_gpu": round(value / world / cpu_rps, 1)}
             if not args.no_train and "rays_per_s" in out.get("train", {}):
-                cpu_train = cpu_train_baseline(sds, 1024, 2)
+                cpu_train = cpu_train_baseline(sds, 1024, 3)
                 out["cpu_baseline"]["train_rays_per_s"] = round(cpu_train, 1)
-                out["cpu_baseline"]["train_sample"] = "2 timed steps (after 1 warm-up) of the oracle's train step, N_rand=1024, 64+128 samples"
+                out["cpu_baseline"]["train_sample"] = "3 timed steps (after 1 warm-up) of the oracle's train step, N_rand=1024, 64+128 samples"
                 out["cpu_baseline"]["train_speedup_per_gpu"] = round(out["train"]["rays_per_s"] / world / cpu_train, 1)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

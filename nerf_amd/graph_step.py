@@ -78,7 +78,7 @@ class GraphedTrainStep:
         # the recorded step re-packs the weight streams into the same buffers on every replay; the modules' host-side
         # cache key cannot see that, so an eager render after a replay must not trust it
         for m in self.models:
-            m._pack_key = None
+            m.invalidate_packs()
 
     def set_lr(self, value: float) -> None:
         for group in self.opt.param_groups:

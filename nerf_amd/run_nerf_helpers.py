@@ -136,6 +136,14 @@ class NeRF(nn.Module):
             self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = None
         return self._flat_vec
 
+    def invalidate_packs(self) -> None:
+        """Forget every packed weight stream; the next query rebuilds them from the parameters.  The cache key is each
+        parameter's (address, version counter), which in-place autograd-visible updates bump; writes that bypass the
+        counter -- `p.data.copy_(...)`, `p.data.mul_(...)`, a HIP-graph replay of an optimiser step, an external loader
+        writing through data_ptr() -- must be followed by this call."""
+        self._pack_key = None
+        self._flat_vec = None
+
     def _packed(self, want_bwd: bool):
         """(forward stream, backward stream or None, flat parameters) of the 32-point-tile kernels."""
         flat = self._flat()
