@@ -217,6 +217,17 @@ int nerf_pack_weights_bwd_bf16x3(int use_viewdirs, int output_ch, const float* p
 int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                         const void* packed_bf16x3, const void* packed_bwd_bf16x3, float* scratch, float* d_params, void* stream);
 
+/* nerf_mlp_bwd_bf16x3 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): no counterpart upstream.  Same arguments and results, bit for bit, minus
+ * the workspace: the dY rows and partial-gradient slabs live in an array the library's code object holds on every
+ * device it is loaded on (about 40 MB per device until the process ends).  Limits: n_pts <= NERF_STATIC_BWD_MAX_PTS
+ * per call, otherwise NERF_E_ARG; the call allocates nothing; every call on one device shares that device's array,
+ * so calls that overlap on one device (two streams, two threads) race -- serialise them. */
+#define NERF_STATIC_BWD_MAX_PTS 2048
+int64_t nerf_mlp_bwd_static_max_points(void);
+int nerf_mlp_bwd_bf16x3_static(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                               const void* packed_bf16x3, const void* packed_bwd_bf16x3, float* d_params, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "mlp_core.hpp"
 #include "mlp_x4.hpp"
+#include <mutex>
 
 // stage 1 on the split-operand kernel (mlp_bwd_bf16x3.hip)
 namespace nerfx3 {
@@ -456,13 +457,20 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
     }
 }
 
+// Upper bound of the slices (= partial-gradient slabs) of one task for `ldp` padded points: a slice is at least eight
+// 32-point chunks long, and there are at most KSPLIT of them.  Every caller that sizes a slab area uses this bound.
+inline int max_slabs(int64_t ldp) {
+    const int64_t by_len = ldp / (8 * 32);
+    return (int)(by_len < 1 ? 1 : (by_len > KSPLIT ? KSPLIT : by_len));
+}
+
 // Slices per task: repeatedly give one more slice to the task whose slices are longest, until the launch
 // has one workgroup per compute unit.  cost = time of one chunk of the task relative to the others
 // (MFMA issue per SIMD, or the operand copy where that is longer).
 void assign_splits(DwTasks& tk, const int* cost, int64_t nchunks, int n_wg) {
     int used = 0;
     for (int i = 0; i < tk.n; ++i) { tk.t[i].nsplit = 1; ++used; }
-    const int cap = (int)(nchunks < KSPLIT ? (nchunks > 0 ? nchunks : 1) : KSPLIT);
+    const int cap = max_slabs(nchunks * KT);
     while (used < n_wg) {
         int best = -1;
         double worst = 0.0;
@@ -645,6 +653,60 @@ int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int
     int rc = nerfx3::launch_bwd_data_x3(n_pts, use_viewdirs, output_ch, d_out, act, packed_x3, packed_bwd_x3, scratch, stream);
     if (rc) return rc;
     return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
+}
+
+
+/* ---- the same backward for callers that cannot allocate ----------------------------------------------------------
+ * Workspace of nerf_mlp_bwd_bf16x3 for up to NERF_STATIC_BWD_MAX_PTS points, held by the code object on every device
+ * that loads the library: the dY rows of those points + the partial-gradient slabs that many points can need. */
+}  // extern "C"
+
+namespace {
+constexpr int64_t STATIC_MAX_PTS = NERF_STATIC_BWD_MAX_PTS;
+constexpr int64_t STATIC_SLABS = STATIC_MAX_PTS / (8 * 32) < KSPLIT ? STATIC_MAX_PTS / (8 * 32) : KSPLIT;
+constexpr int64_t STATIC_SLAB_FLOATS = 595904;   // slab_floats() of the largest supported network (view branch); checked per call
+constexpr int64_t STATIC_FLOATS = (int64_t)scr_rows(1) * STATIC_MAX_PTS + STATIC_SLABS * STATIC_SLAB_FLOATS;
+static __device__ __align__(256) float scratch[STATIC_FLOATS];
+
+// Device address of `scratch` on each device: the array's name is a host-side handle, not a pointer a kernel can use.
+constexpr int MAX_DEVICES = 64;
+float* g_scratch_ptr[MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+int static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
+        return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_bf16x3_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_bf16x3_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t nerf_mlp_bwd_static_max_points(void) { return STATIC_MAX_PTS; }
+
+int nerf_mlp_bwd_bf16x3_static(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                               const void* packed_x3, const void* packed_bwd_x3, float* d_params, void* stream_) {
+    NERF_REQUIRE(n_pts >= 0 && n_pts <= STATIC_MAX_PTS,
+                 "nerf_mlp_bwd_bf16x3_static: n_pts=%lld exceeds the built-in workspace (at most %lld points per call; "
+                 "use nerf_mlp_bwd_bf16x3 with a caller workspace for more)", (long long)n_pts, (long long)STATIC_MAX_PTS);
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd_bf16x3_static: output_ch=%d not in 1..8", output_ch);
+    NERF_REQUIRE(slab_floats(use_viewdirs, output_ch) <= STATIC_SLAB_FLOATS && scr_rows(use_viewdirs) <= scr_rows(1),
+                 "nerf_mlp_bwd_bf16x3_static: network shape larger than the built-in workspace");
+    float* ws = nullptr;
+    int rc = static_scratch(&ws);
+    if (rc) return rc;
+    return nerf_mlp_bwd_bf16x3(n_pts, d_out, act, use_viewdirs, output_ch, packed_x3, packed_bwd_x3, ws, d_params, stream_);
 }
 
 }  // extern "C"
