@@ -217,6 +217,17 @@ int nerf_pack_weights_bwd_bf16x3(int use_viewdirs, int output_ch, const float* p
 int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                         const void* packed_bf16x3, const void* packed_bwd_bf16x3, float* scratch, float* d_params, void* stream);
 
+/* The two stages of nerf_mlp_bwd_bf16x3 as separate calls (same arguments; the stages communicate through `scratch`
+ * only, so a caller can time them, or overlap other work between them): _data fills the dY rows of every layer
+ * (what autograd calls grad of the pre-activations, run_nerf_helpers.py:109-133 backwards), _weights turns them and the
+ * saved activations into d_params = dY X^T per layer (split operands as well: both operands split exactly into three
+ * bf16 pieces while they are staged, six piece products, fp32 sums, partial sums per slice of the point range added in
+ * fixed order). */
+int nerf_mlp_bwd_data_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                             const void* packed_bf16x3, const void* packed_bwd_bf16x3, float* scratch, void* stream);
+int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdirs, int output_ch, float* scratch,
+                                float* d_params, void* stream);
+
 /* nerf_mlp_bwd_bf16x3 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): no counterpart upstream.  Same arguments and results, bit for bit, minus
  * the workspace: the dY rows and partial-gradient slabs live in an array the library's code object holds on every

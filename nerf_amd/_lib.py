@@ -67,6 +67,8 @@ SIGNATURES = {
     "nerf_mlp_packed_bwd_bf16x3_bytes": (_l, [_i]),
     "nerf_pack_weights_bwd_bf16x3": (_i, [_i, _i, _p, _p, _p]),
     "nerf_mlp_bwd_bf16x3": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "nerf_mlp_bwd_data_bf16x3": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "nerf_mlp_bwd_weights_bf16x3": (_i, [_l, _p, _i, _i, _p, _p, _p]),
     "nerf_mlp_bwd_static_max_points": (_l, []),
     "nerf_mlp_bwd_bf16x3_static": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_mlp_packed_bf16_bytes": (_l, [_i]),

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "mlp_core.hpp"
 #include "mlp_x4.hpp"
+#include "mlp_dw.hpp"
 #include <mutex>
 
 // stage 1 on the split-operand kernel (mlp_bwd_bf16x3.hip)
@@ -457,20 +458,13 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
     }
 }
 
-// Upper bound of the slices (= partial-gradient slabs) of one task for `ldp` padded points: a slice is at least eight
-// 32-point chunks long, and there are at most KSPLIT of them.  Every caller that sizes a slab area uses this bound.
-inline int max_slabs(int64_t ldp) {
-    const int64_t by_len = ldp / (8 * 32);
-    return (int)(by_len < 1 ? 1 : (by_len > KSPLIT ? KSPLIT : by_len));
-}
-
 // Slices per task: repeatedly give one more slice to the task whose slices are longest, until the launch
 // has one workgroup per compute unit.  cost = time of one chunk of the task relative to the others
 // (MFMA issue per SIMD, or the operand copy where that is longer).
 void assign_splits(DwTasks& tk, const int* cost, int64_t nchunks, int n_wg) {
     int used = 0;
     for (int i = 0; i < tk.n; ++i) { tk.t[i].nsplit = 1; ++used; }
-    const int cap = max_slabs(nchunks * KT);
+    const int cap = nerfdw::max_slabs(nchunks * KT);
     while (used < n_wg) {
         int best = -1;
         double worst = 0.0;
@@ -555,9 +549,15 @@ static int run_dw(int64_t ldp, int use_viewdirs, int output_ch, const ParamOffse
     rc = launched("nerf_mlp_bwd (dW)");
     if (rc) return rc;
 
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(1024), dim3(256), 0, stream, slabs, slab, po.total, nslabs, d_params);
+    return nerfdw::reduce_slabs(slabs, slab, po.total, nslabs, d_params, stream);
+}
+
+namespace nerfdw {
+int reduce_slabs(const float* slabs, int64_t slab_stride, int64_t n, int nslabs, float* d_params, hipStream_t stream) {
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(1024), dim3(256), 0, stream, slabs, slab_stride, n, nslabs, d_params);
     return launched("nerf_mlp_bwd (reduce)");
 }
+}  // namespace nerfdw
 
 extern "C" {
 
@@ -629,32 +629,55 @@ int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use
     return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
 }
 
-/* nerf_mlp_bwd with the backward-data stage on the split-operand kernel: packed_x3 (nerf_pack_weights_bf16x3, for the
- * fp32 tables behind it) and packed_bwd_x3 (nerf_pack_weights_bwd_bf16x3) in place of the fp32 streams. */
-int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
-                        const void* packed_x3, const void* packed_bwd_x3, float* scratch, float* d_params, void* stream_) {
-    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd_bf16x3: n_pts=%lld", (long long)n_pts);
-    NERF_REQUIRE(d_params, "nerf_mlp_bwd_bf16x3: null d_params");
-    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd_bf16x3: output_ch=%d not in 1..8", output_ch);
+/* The parameter-gradient pass on the split-operand kernels, stage by stage (the stages only communicate through
+ * `scratch`; nerf_mlp_bwd_bf16x3 runs both). */
+static int check_bwd_x3(const char* who, int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                        const void* packed_x3, const void* packed_bwd_x3, const float* scratch) {
+    NERF_REQUIRE(n_pts >= 0, "%s: n_pts=%lld", who, (long long)n_pts);
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "%s: output_ch=%d not in 1..8", who, output_ch);
+    if (n_pts == 0) return 0;
+    NERF_REQUIRE(d_out && act && packed_x3 && packed_bwd_x3 && scratch, "%s: null pointer", who);
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch) |
+                   reinterpret_cast<uintptr_t>(packed_x3) | reinterpret_cast<uintptr_t>(packed_bwd_x3)) & 15) == 0,
+                 "%s: buffers must be 16-byte aligned", who);
+    NERF_REQUIRE(padded_points(n_pts) / TILE_PTS <= 0x7fffffff, "%s: n_pts=%lld too large for one call", who, (long long)n_pts);
+    return 0;
+}
+
+int nerf_mlp_bwd_data_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                             const void* packed_x3, const void* packed_bwd_x3, float* scratch, void* stream_) {
+    int rc = check_bwd_x3("nerf_mlp_bwd_data_bf16x3", n_pts, d_out, act, use_viewdirs, output_ch, packed_x3, packed_bwd_x3, scratch);
+    if (rc || n_pts == 0) return rc;
+    return nerfx3::launch_bwd_data_x3(n_pts, use_viewdirs, output_ch, d_out, act, packed_x3, packed_bwd_x3, scratch, as_stream(stream_));
+}
+
+int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdirs, int output_ch, float* scratch,
+                                float* d_params, void* stream_) {
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd_weights_bf16x3: n_pts=%lld", (long long)n_pts);
+    NERF_REQUIRE(d_params, "nerf_mlp_bwd_weights_bf16x3: null d_params");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd_weights_bf16x3: output_ch=%d not in 1..8", output_ch);
     hipStream_t stream = as_stream(stream_);
     const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
     if (n_pts == 0) {
         hipError_t e0 = hipMemsetAsync(d_params, 0, po.total * sizeof(float), stream);
-        return e0 == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd_bf16x3: memset: %s", hipGetErrorString(e0));
+        return e0 == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd_weights_bf16x3: memset: %s", hipGetErrorString(e0));
     }
-    NERF_REQUIRE(d_out && act && packed_x3 && packed_bwd_x3 && scratch, "nerf_mlp_bwd_bf16x3: null pointer");
-    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch) |
-                   reinterpret_cast<uintptr_t>(packed_x3) | reinterpret_cast<uintptr_t>(packed_bwd_x3)) & 15) == 0,
-                 "nerf_mlp_bwd_bf16x3: buffers must be 16-byte aligned");
+    NERF_REQUIRE(act && scratch, "nerf_mlp_bwd_weights_bf16x3: null pointer");
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0,
+                 "nerf_mlp_bwd_weights_bf16x3: buffers must be 16-byte aligned");
     const int64_t ldp = padded_points(n_pts);
-    NERF_REQUIRE(ldp / TILE_PTS <= 0x7fffffff, "nerf_mlp_bwd_bf16x3: n_pts=%lld too large for one call", (long long)n_pts);
     const int64_t slab = slab_floats(use_viewdirs, output_ch);
     float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
-    int rc = nerfx3::launch_bwd_data_x3(n_pts, use_viewdirs, output_ch, d_out, act, packed_x3, packed_bwd_x3, scratch, stream);
-    if (rc) return rc;
-    return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
+    return nerfdw::run_dw_x3(ldp, use_viewdirs, output_ch, act, scratch, slabs, slab, d_params, stream);
 }
 
+int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                        const void* packed_x3, const void* packed_bwd_x3, float* scratch, float* d_params, void* stream_) {
+    NERF_REQUIRE(d_params, "nerf_mlp_bwd_bf16x3: null d_params");
+    int rc = nerf_mlp_bwd_data_bf16x3(n_pts, d_out, act, use_viewdirs, output_ch, packed_x3, packed_bwd_x3, scratch, stream_);
+    if (rc) return rc;
+    return nerf_mlp_bwd_weights_bf16x3(n_pts, act, use_viewdirs, output_ch, scratch, d_params, stream_);
+}
 
 /* ---- the same backward for callers that cannot allocate ----------------------------------------------------------
  * Workspace of nerf_mlp_bwd_bf16x3 for up to NERF_STATIC_BWD_MAX_PTS points, held by the code object on every device

@@ -1,0 +1,24 @@
+// Pieces shared by the weight-gradient stages of the parameter-gradient pass (mlp_bwd.hip: fp32 matrix instruction;
+// mlp_dw_x3.hip: split operands on the bf16 matrix instruction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "mlp_layout.hpp"
+
+namespace nerfdw {
+
+// Upper bound of the slices (= partial-gradient slabs) of one task for `ldp` padded points: a slice is at least 256
+// points long, and there are at most KSPLIT of them.  Every caller that sizes a slab area uses this bound.
+inline int max_slabs(int64_t ldp) {
+    const int64_t by_len = ldp / 256;
+    return (int)(by_len < 1 ? 1 : (by_len > nerflayout::KSPLIT ? nerflayout::KSPLIT : by_len));
+}
+
+// d_params[i] = sum over the first nslabs slabs, in slab order (mlp_bwd.hip)
+int reduce_slabs(const float* slabs, int64_t slab_stride, int64_t n, int nslabs, float* d_params, hipStream_t stream);
+
+// all weight and bias gradients from the saved activations `act` and the dY rows in `scratch` (mlp_dw_x3.hip)
+int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
+              float* d_params, hipStream_t stream);
+
+}  // namespace nerfdw

@@ -1,0 +1,352 @@
+// Weight gradients of the fused MLP, dW_l = dY_l X_l^T (a reduction over sample points), with fp32 accuracy on the
+// bf16 matrix instruction: the third stage of the parameter-gradient pass (autograd of run_nerf_helpers.py:109-133),
+// on the split-operand scheme of mlp_fwd_bf16x3.hip.
+//
+// Both operands live in HBM as fp32 in the blocked layout of mlp_layout.hpp ([128-point tile][row / 4][point][row % 4]).
+// A workgroup (8 waves, two per SIMD) owns one task -- a weight matrix, or matrices that share an operand -- for one
+// slice of the point range and walks it in stages of 16 points:
+//   * staging: a thread loads 16 bytes = four consecutive rows of one point (128-byte runs per row group and
+//     instruction), splits the four values EXACTLY into three bf16 pieces (mlp_x3.hpp) and writes 8 bytes per piece
+//     into an LDS image [piece][point][row] whose point stride is 32 bytes past a multiple of 256;
+//   * fragments: ds_read_b64_tr_b16 reads a 4-point x 16-row block of the image transposed, i.e. as four k-slots
+//     (points) of 16 operand rows, without bank conflicts; two such reads of DIFFERENT pieces make one 8-slot fragment,
+//     so one v_mfma_f32_16x16x32_bf16 over 16 points sums two piece products:
+//         [dY.hi | dY.mid] x [X.hi | X.hi]  = hi.hi  + mid.hi
+//         [dY.hi | dY.mid] x [X.mid | X.mid] = hi.mid + mid.mid
+//         [dY.hi | dY.lo]  x [X.lo | X.hi]  = hi.lo  + lo.hi        -> the six largest of the nine piece products;
+//   * the loads of stage s+2 are issued as soon as the registers of stage s+1 have been split, so every load has a whole
+//     stage of matrix work to arrive; two LDS images alternate, one barrier per stage.
+// Bias gradients are fp32 row sums of dY taken in the staging path.  Partial results go to per-slice slabs that a last
+// kernel sums in fixed order (bitwise reproducible, no float atomics).
+#include "common.hpp"
+#include "mlp_core.hpp"
+#include "mlp_x3.hpp"
+#include "mlp_dw.hpp"
+
+using namespace nerfhip;
+using namespace nerflayout;
+using namespace nerfmlp;
+using namespace nerfx3;
+
+namespace {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DWX_THREADS = 512;
+constexpr int SP = 16;                 // points per stage
+constexpr int MAX_LOADS = 5;
+
+// What a kind of task looks like to a workgroup.  The LDS image holds 128 * NL operand rows per point: the dY rows
+// first (A_TILES tiles of 16), then the input rows; a wave multiplies TM row tiles by TN column tiles.
+template <int KIND> struct DwKind;
+template <> struct DwKind<0> { static constexpr int NL = 4, A_TILES = 16, TM = 8, TN = 4, NBIAS = 2; };   // hidden layer 256 x 256
+template <> struct DwKind<1> { static constexpr int NL = 5, A_TILES = 32, TM = 4, TN = 4, NBIAS = 2; };   // dY0 ++ dY5 x encoded position
+template <> struct DwKind<2> { static constexpr int NL = 4, A_TILES = 8, TM = 4, TN = 5, NBIAS = 1; };    // views layer x (feature ++ direction)
+template <> struct DwKind<3> { static constexpr int NL = 3, A_TILES = 8, TM = 1, TN = 2, NBIAS = 1; };    // heads: <= 8 rows
+
+template <int NL> struct Image {
+    static constexpr int ROWS = 128 * NL;
+    static constexpr int PS = 2 * ROWS + 32;      // bytes per point and piece
+    static constexpr int PL = SP * PS;            // bytes per piece
+    static constexpr int STAGE = 3 * PL;
+};
+constexpr size_t dwx_lds_bytes(int nl) { return 2 * 3 * (size_t)SP * (256 * nl + 32); }
+
+struct DwxTask {
+    int kind;
+    int ld_src[MAX_LOADS];     // per load of 32 row groups: 0 = gradient workspace, 1 = saved activations
+    int ld_grp[MAX_LOADS];     // first row group
+    int ld_n[MAX_LOADS];       // valid row groups (the others repeat the first: nothing reads them)
+    int M, N;                  // valid rows / columns of the product(s)
+    int ldc, ldc2;             // row strides in the flat parameter vector
+    int64_t out, out2;         // W[0][0] of the product, and of the second one (kind 1: layer 5's encoded-input columns)
+    int64_t bias;              // bias of the first dY run, or -1
+    int first, nsplit;         // workgroups [first, first + nsplit) slice the point range
+};
+struct DwxTasks {
+    DwxTask t[14];
+    int n;
+};
+
+__device__ __forceinline__ bf16x4 tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+template <int KIND>
+__device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t nchunks, int64_t tile_floats,
+                                         const float* __restrict__ act, const float* __restrict__ scr,
+                                         float* __restrict__ slab, char* smem) {
+    using K = DwKind<KIND>;
+    using Im = Image<K::NL>;
+    constexpr int NL = K::NL, TM = K::TM, TN = K::TN, NBIAS = K::NBIAS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+
+    const int64_t per = (nchunks + task.nsplit - 1) / task.nsplit;
+    const int64_t c0 = split * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
+
+    // ---- which tiles this wave multiplies, and where its block of the product goes
+    int a_tile0, b_tile0, row0, col0, ldc = task.ldc;
+    int64_t out = task.out;
+    bool idle = false;
+    if constexpr (KIND == 0) {
+        a_tile0 = 8 * (wave >> 2); b_tile0 = 4 * (wave & 3); row0 = 16 * a_tile0; col0 = 16 * b_tile0;
+    } else if constexpr (KIND == 1) {
+        a_tile0 = 4 * wave; b_tile0 = 0; row0 = 64 * (wave & 3); col0 = 0;
+        if (wave >= 4) { out = task.out2; ldc = task.ldc2; }
+    } else if constexpr (KIND == 2) {
+        a_tile0 = 4 * (wave >> 2); b_tile0 = 5 * (wave & 3); row0 = 16 * a_tile0; col0 = 16 * b_tile0;
+    } else {
+        a_tile0 = 0; b_tile0 = 2 * wave; row0 = 0; col0 = 32 * wave;
+        idle = col0 >= task.N;
+    }
+
+    // ---- staging map: thread -> (row group 32 k + rgi, point pt) of every load k
+    const int pt = 8 * (wave & 1) + (lane & 7), rgi = 8 * (wave >> 1) + (lane >> 3);
+    const float* gsrc[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const float* base = task.ld_src[k] ? act : scr;
+        gsrc[k] = base + (int64_t)(task.ld_grp[k] + (rgi < task.ld_n[k] ? rgi : 0)) * GROUP_FLOATS + pt * 4;
+    }
+    const int wr_off = pt * Im::PS + 8 * rgi;                       // + piece * PL + 256 k
+    // ---- fragment reads: lane 4q+p of group g addresses point 4g+q, rows 4p..4p+3 of a 16-row tile
+    const int rd_off = (4 * g + ((lane >> 2) & 3)) * Im::PS + 8 * (lane & 3);
+    const int rd_a = rd_off + 32 * a_tile0, rd_b = rd_off + 32 * (K::A_TILES + b_tile0);
+
+    f32x4 stage[NL];
+    auto issue = [&]<int k>(int64_t chunk) {
+        const int64_t off = (chunk >> 3) * tile_floats + (chunk & 7) * (SP * 4);
+        stage[k] = *reinterpret_cast<const f32x4*>(gsrc[k] + off);
+    };
+    float bsum[NBIAS][4];
+#pragma unroll
+    for (int k = 0; k < NBIAS; ++k) bsum[k][0] = bsum[k][1] = bsum[k][2] = bsum[k][3] = 0.0f;
+    const bool want_bias = task.bias >= 0;
+    // split the four rows of load k and write the pieces into image `img`
+    auto commit = [&]<int k>(char* img, bool count) {
+        const f32x4 v = stage[k];
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 a, b, c;
+            split3(v[e], a, b, c);
+            h[e] = a; m[e] = b; l[e] = c;
+        }
+        char* dst = img + wr_off + 256 * k;
+        *reinterpret_cast<bf16x4*>(dst) = h;
+        *reinterpret_cast<bf16x4*>(dst + Im::PL) = m;
+        *reinterpret_cast<bf16x4*>(dst + 2 * Im::PL) = l;
+        if constexpr (k < NBIAS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[k][e] += count ? v[e] : 0.0f;
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    if (c0 < c1) {
+        static_for<NL>([&]<int k>() { issue.template operator()<k>(c0); });
+        static_for<NL>([&]<int k>() { commit.template operator()<k>(smem, true); });
+        static_for<NL>([&]<int k>() { issue.template operator()<k>(c0 + 1 < c1 ? c0 + 1 : c0); });
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    for (int64_t c = c0; c < c1; ++c) {
+        const int buf = (int)((c - c0) & 1);
+        const char* cur = smem + buf * Im::STAGE;
+        char* nxt = smem + (buf ^ 1) * Im::STAGE;
+        const bool more = c + 1 < c1;                    // the registers hold stage c + 1 (or a repeat of the last one)
+        const int64_t c2 = c + 2 < c1 ? c + 2 : c1 - 1;
+
+        // the column fragments of this stage: [hi | hi], [mid | mid], [lo | hi]
+        bf16x8 B1[TN], B2[TN], B3[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const char* p = cur + rd_b + 32 * j;
+            B1[j] = cat8(tr16(p), tr16(p));
+            B2[j] = cat8(tr16(p + Im::PL), tr16(p + Im::PL));
+            B3[j] = cat8(tr16(p + 2 * Im::PL), tr16(p));
+        }
+        bf16x8 A1[2], A2[2];                             // [hi | mid], [hi | lo] of a row tile, read one tile ahead
+        auto read_a = [&]<int i>() {
+            const char* p = cur + rd_a + 32 * i;
+            A1[i & 1] = cat8(tr16(p), tr16(p + Im::PL));
+            A2[i & 1] = cat8(tr16(p), tr16(p + 2 * Im::PL));
+        };
+        read_a.template operator()<0>();
+        static_for<TM>([&]<int i>() {
+            if constexpr (i + 1 < TM) read_a.template operator()<i + 1>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!idle) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = mfma16(A1[i & 1], B2[j], acc[i][j]);
+                    acc[i][j] = mfma16(A2[i & 1], B3[j], acc[i][j]);
+                    acc[i][j] = mfma16(A1[i & 1], B1[j], acc[i][j]);
+                }
+            }
+            // staging of stage c + 1 behind the matrix work: load k is split when row tile slot(k) multiplies
+            static_for<NL>([&]<int k>() {
+                if constexpr (((k + 1) * TM - 1) / NL == i) {
+                    commit.template operator()<k>(nxt, more);
+                    issue.template operator()<k>(c2);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- this slice's block of the product -> its slab
+    if (!idle) {
+        float* o = slab + out;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = col0 + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * i + 4 * g + r;
+                    if (row < task.M && col < task.N) o[(int64_t)row * ldc + col] = acc[i][j][r];
+                }
+            }
+    }
+    // ---- bias gradients: per-thread row sums -> LDS [row][point] -> one thread per row adds the 16 points in order
+    if (want_bias) {
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < NBIAS; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(4 * (32 * k + rgi) + e) * SP + pt] = bsum[k][e];
+        __syncthreads();
+        if (tid < 128 * NBIAS && tid < task.M) {
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < SP; ++q) s += red[tid * SP + q];
+            slab[task.bias + tid] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(DWX_THREADS, 2)
+k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __restrict__ act, const float* __restrict__ scr,
+        float* __restrict__ slabs, int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem_dw[];
+    int ti = 0;
+    for (int i = 1; i < tasks.n; ++i)
+        if ((int)blockIdx.x >= tasks.t[i].first) ti = i;
+    const DwxTask& task = tasks.t[ti];
+    const int split = (int)blockIdx.x - task.first;
+    float* slab = slabs + (int64_t)split * slab_stride;
+    switch (task.kind) {
+        case 0: dwx_loop<0>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
+        case 1: dwx_loop<1>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
+        case 2: dwx_loop<2>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
+        default: dwx_loop<3>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
+    }
+}
+
+}  // namespace
+
+namespace nerfdw {
+
+// dW = dY X^T over all layers in one launch on the split-operand kernel, then the fixed-order sum of the partial slabs.
+int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
+              float* d_params, hipStream_t stream) {
+    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
+    const int SCR_HEAD = scr_head(use_viewdirs), SCR_HEAD2 = SCR_HEAD + 32;
+    DwxTasks tk{};
+    int cost[14];
+    int nt = 0;
+    auto load = [](DwxTask& t, int k, int src, int row, int rows) { t.ld_src[k] = src; t.ld_grp[k] = row / 4; t.ld_n[k] = rows / 4 > 32 ? 32 : rows / 4; };
+    auto big = [&](int a_row, int b_row, int ldc, int64_t out, int64_t bias) {
+        DwxTask t{};
+        t.kind = 0;
+        load(t, 0, 0, a_row, 128); load(t, 1, 0, a_row + 128, 128); load(t, 2, 1, b_row, 128); load(t, 3, 1, b_row + 128, 128);
+        t.M = 256; t.N = 256; t.ldc = ldc; t.out = out; t.bias = bias;
+        cost[nt] = 16; tk.t[nt++] = t;
+    };
+    for (int l = 1; l < 8; ++l)
+        big(SCR_H0 + 256 * l, ACT_H0 + 256 * (l - 1), (l == 5) ? W + IN_PTS : W, po.pts_w[l] + (l == 5 ? IN_PTS : 0), po.pts_b[l]);
+    if (use_viewdirs) big(SCR_FEAT, ACT_H0 + 256 * 7, W, po.feat_w, po.feat_b);
+    {   // encoded positions feed layers 0 and 5
+        DwxTask t{};
+        t.kind = 1;
+        load(t, 0, 0, SCR_H0, 128); load(t, 1, 0, SCR_H0 + 128, 128);
+        load(t, 2, 0, SCR_H0 + 256 * 5, 128); load(t, 3, 0, SCR_H0 + 256 * 5 + 128, 128);
+        load(t, 4, 1, ACT_ENC_PTS, 64);
+        t.M = 256; t.N = IN_PTS; t.ldc = IN_PTS; t.ldc2 = W + IN_PTS; t.out = po.pts_w[0]; t.out2 = po.pts_w[5]; t.bias = po.pts_b[0];
+        cost[nt] = 13; tk.t[nt++] = t;
+    }
+    if (use_viewdirs) {
+        DwxTask t{};   // views layer: dY x (feature ++ encoded direction); the weight's 283 columns are contiguous
+        t.kind = 2;
+        load(t, 0, 0, SCR_VIEWS, 128); load(t, 1, 1, ACT_FEAT, 128); load(t, 2, 1, ACT_FEAT + 128, 128); load(t, 3, 1, ACT_ENC_DIRS, 32);
+        t.M = 128; t.N = W + IN_DIRS; t.ldc = po.views_in; t.out = po.views_w; t.bias = po.views_b;
+        cost[nt] = 12; tk.t[nt++] = t;
+        DwxTask a{};   // alpha: dL/d(sigma) x h7
+        a.kind = 3;
+        load(a, 0, 0, SCR_HEAD2, 8); load(a, 1, 1, ACT_H0 + 256 * 7, 128); load(a, 2, 1, ACT_H0 + 256 * 7 + 128, 128);
+        a.M = 1; a.N = 256; a.ldc = W; a.out = po.alpha_w; a.bias = po.alpha_b;
+        cost[nt] = 6; tk.t[nt++] = a;
+        DwxTask c{};   // rgb: dL/d(rgb) x views hidden
+        c.kind = 3;
+        load(c, 0, 0, SCR_HEAD, 8); load(c, 1, 1, ACT_VIEWS, 128); load(c, 2, 1, ACT_VIEWS, 0);
+        c.M = 3; c.N = 128; c.ldc = W / 2; c.out = po.rgb_w; c.bias = po.rgb_b;
+        cost[nt] = 4; tk.t[nt++] = c;
+    } else {
+        DwxTask a{};   // output_linear: dL/d(out) x h7
+        a.kind = 3;
+        load(a, 0, 0, SCR_HEAD, 8); load(a, 1, 1, ACT_H0 + 256 * 7, 128); load(a, 2, 1, ACT_H0 + 256 * 7 + 128, 128);
+        a.M = output_ch; a.N = 256; a.ldc = W; a.out = po.out_w; a.bias = po.out_b;
+        cost[nt] = 6; tk.t[nt++] = a;
+    }
+    tk.n = nt;
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu < nt) n_cu = nt;
+    const int64_t nchunks = ldp / SP;
+    // slices per task: one more slice to the task whose slices are longest until the launch is one workgroup per CU
+    const int cap = max_slabs(ldp);
+    int used = 0;
+    for (int i = 0; i < nt; ++i) { tk.t[i].nsplit = 1; ++used; }
+    while (used < n_cu) {
+        int best = -1;
+        double worst = 0.0;
+        for (int i = 0; i < nt; ++i) {
+            if (tk.t[i].nsplit >= cap) continue;
+            const double per = (double)cost[i] / tk.t[i].nsplit;
+            if (per > worst) { worst = per; best = i; }
+        }
+        if (best < 0) break;
+        ++tk.t[best].nsplit;
+        ++used;
+    }
+    int n_wg = 0, nslabs = 0;
+    for (int i = 0; i < nt; ++i) {
+        tk.t[i].first = n_wg;
+        n_wg += tk.t[i].nsplit;
+        if (tk.t[i].nsplit > nslabs) nslabs = tk.t[i].nsplit;
+    }
+    // slab entries no task covers (parameters that receive no gradient) must read as zero in the reduction
+    hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslabs * slab * sizeof(float), stream);
+    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
+    const size_t lds = dwx_lds_bytes(MAX_LOADS);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_dw_x3, dim3(n_wg), dim3(DWX_THREADS), lds, stream, tk, nchunks,
+                       (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab);
+    int rc = launched("nerf_mlp_bwd (dW, split operands)");
+    if (rc) return rc;
+    return reduce_slabs(slabs, slab, po.total, nslabs, d_params, stream);
+}
+
+}  // namespace nerfdw

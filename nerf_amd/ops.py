@@ -501,10 +501,13 @@ def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tens
     n_pts = d_out.shape[0]
     scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
     d_flat = torch.empty_like(flat)
-    with torch.cuda.device(d_out.device), _timed("mlp_bwd", n_pts):
-        check(lib.nerf_mlp_bwd_bf16x3(n_pts, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
-                                      packed_x3.data_ptr(), packed_bwd_x3.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(),
-                                      _stream()))
+    with torch.cuda.device(d_out.device):
+        with _timed("mlp_bwd_data", n_pts):
+            check(lib.nerf_mlp_bwd_data_bf16x3(n_pts, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
+                                               packed_x3.data_ptr(), packed_bwd_x3.data_ptr(), scratch.data_ptr(), _stream()))
+        with _timed("mlp_bwd_dw", n_pts):
+            check(lib.nerf_mlp_bwd_weights_bf16x3(n_pts, act.data_ptr(), int(use_viewdirs), output_ch, scratch.data_ptr(),
+                                                  d_flat.data_ptr(), _stream()))
     return d_flat
 
 
