@@ -4,18 +4,24 @@
 //
 // Both operands live in HBM as fp32 in the blocked layout of mlp_layout.hpp ([128-point tile][row / 4][point][row % 4]).
 // A workgroup (8 waves, two per SIMD) owns one task -- a weight matrix, or matrices that share an operand -- for one
-// slice of the point range and walks it in stages of 16 points:
+// slice of the point range and walks it in stages of 16 points (one k-step of v_mfma_f32_32x32x16_bf16):
 //   * staging: a thread loads 16 bytes = four consecutive rows of one point (128-byte runs per row group and
 //     instruction), splits the four values EXACTLY into three bf16 pieces (mlp_x3.hpp) and writes 8 bytes per piece
-//     into an LDS image [piece][point][row] whose point stride is 32 bytes past a multiple of 256;
+//     into an LDS image [piece][point][row]; the point stride is 64 bytes past a multiple of 256 and the 8-byte chunks
+//     of a 64-byte group are permuted by the point index, which makes both these writes and the reads below free of
+//     bank conflicts;
 //   * fragments: ds_read_b64_tr_b16 reads a 4-point x 16-row block of the image transposed, i.e. as four k-slots
-//     (points) of 16 operand rows, without bank conflicts; two such reads of DIFFERENT pieces make one 8-slot fragment,
-//     so one v_mfma_f32_16x16x32_bf16 over 16 points sums two piece products:
-//         [dY.hi | dY.mid] x [X.hi | X.hi]  = hi.hi  + mid.hi
-//         [dY.hi | dY.mid] x [X.mid | X.mid] = hi.mid + mid.mid
-//         [dY.hi | dY.lo]  x [X.lo | X.hi]  = hi.lo  + lo.hi        -> the six largest of the nine piece products;
-//   * the loads of stage s+2 are issued as soon as the registers of stage s+1 have been split, so every load has a whole
-//     stage of matrix work to arrive; two LDS images alternate, one barrier per stage.
+//     (points) of 16 operand rows; two reads = the 8 k-slots of a lane; six matrix instructions per tile pair rebuild
+//     the product from the piece products hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid;
+//   * two register sets hold the loads of the next two stages (64 KB per compute unit in flight: with one stage in
+//     flight the kernel was bound by memory latency at 3 TB/s); a set is split behind the matrix work of the stage
+//     before its own and re-requested at once; two LDS images alternate, one barrier per stage.
+// Measured on 1.57 M points (tools/time_dw.py, tools/power_probe.sh): 12.3 ms at a 1.67 GHz shader clock; without the HBM
+// loads 7.7 ms at 2.03 GHz (84 % of the matrix pipe's cycles busy); loads and split alone 8.0 ms at 2.19 GHz (3.9 TB/s):
+// the board's power limit, not latency or issue slots, bounds the kernel -- the two parts add up instead of overlapping,
+// whatever the prefetch depth (one or two stages in registers, or a seven-deep LDS-DMA ring: 12.3-13.5 ms).
+// Switches for such ablation builds (tools/ab_dw.sh; the product defines none): DWX_NO_LOAD (stages re-use their first
+// loads), DWX_NO_MFMA, DWX_STREAM_ONLY (no LDS image: loads, split and bias sums only).
 // Bias gradients are fp32 row sums of dY taken in the staging path.  Partial results go to per-slice slabs that a last
 // kernel sums in fixed order (bitwise reproducible, no float atomics).
 #include "common.hpp"
@@ -37,20 +43,21 @@ constexpr int SP = 16;                 // points per stage
 constexpr int MAX_LOADS = 5;
 
 // What a kind of task looks like to a workgroup.  The LDS image holds 128 * NL operand rows per point: the dY rows
-// first (A_TILES tiles of 16), then the input rows; a wave multiplies TM row tiles by TN column tiles.
+// first (A_TILES tiles of 32), then the input rows; a wave multiplies TM row tiles by TN column tiles (32 x 32 each).
 template <int KIND> struct DwKind;
-template <> struct DwKind<0> { static constexpr int NL = 4, A_TILES = 16, TM = 8, TN = 4, NBIAS = 2; };   // hidden layer 256 x 256
-template <> struct DwKind<1> { static constexpr int NL = 5, A_TILES = 32, TM = 4, TN = 4, NBIAS = 2; };   // dY0 ++ dY5 x encoded position
-template <> struct DwKind<2> { static constexpr int NL = 4, A_TILES = 8, TM = 4, TN = 5, NBIAS = 1; };    // views layer x (feature ++ direction)
-template <> struct DwKind<3> { static constexpr int NL = 3, A_TILES = 8, TM = 1, TN = 2, NBIAS = 1; };    // heads: <= 8 rows
+template <> struct DwKind<0> { static constexpr int NL = 4, A_TILES = 8, TM = 4, TN = 2, NBIAS = 2; };    // hidden layer 256 x 256
+template <> struct DwKind<1> { static constexpr int NL = 5, A_TILES = 16, TM = 2, TN = 2, NBIAS = 2; };   // dY0 ++ dY5 x encoded position
+template <> struct DwKind<2> { static constexpr int NL = 4, A_TILES = 4, TM = 1, TN = 5, NBIAS = 1; };    // views layer x (feature ++ direction)
+template <> struct DwKind<3> { static constexpr int NL = 3, A_TILES = 4, TM = 1, TN = 1, NBIAS = 1; };    // heads: <= 8 rows
 
 template <int NL> struct Image {
     static constexpr int ROWS = 128 * NL;
-    static constexpr int PS = 2 * ROWS + 32;      // bytes per point and piece
+    static constexpr int PS = 2 * ROWS + 64;      // bytes per point and piece
     static constexpr int PL = SP * PS;            // bytes per piece
     static constexpr int STAGE = 3 * PL;
 };
-constexpr size_t dwx_lds_bytes(int nl) { return 2 * 3 * (size_t)SP * (256 * nl + 32); }
+constexpr size_t DWX_LDS_BYTES = 2 * (size_t)Image<MAX_LOADS>::STAGE;
+static_assert(DWX_LDS_BYTES <= 160 * 1024, "LDS of one compute unit");
 
 struct DwxTask {
     int kind;
@@ -72,6 +79,11 @@ __device__ __forceinline__ bf16x4 tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// position of 8-byte chunk `c` (four rows) inside its 64-byte group for point `pt`
+__device__ __forceinline__ int swz(int c, int pt) { return c ^ (((pt >> 1) & 3) << 1); }
 
 template <int KIND>
 __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t nchunks, int64_t tile_floats,
@@ -83,22 +95,23 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
 
-    const int64_t per = (nchunks + task.nsplit - 1) / task.nsplit;
+    // a slice is an even number of stages (the stage loop is unrolled by two; nchunks is a multiple of eight)
+    const int64_t per = ((nchunks + task.nsplit - 1) / task.nsplit + 1) & ~(int64_t)1;
     const int64_t c0 = split * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
 
-    // ---- which tiles this wave multiplies, and where its block of the product goes
+    // ---- which 32 x 32 tiles this wave multiplies, and where its block of the product goes
     int a_tile0, b_tile0, row0, col0, ldc = task.ldc;
     int64_t out = task.out;
     bool idle = false;
     if constexpr (KIND == 0) {
-        a_tile0 = 8 * (wave >> 2); b_tile0 = 4 * (wave & 3); row0 = 16 * a_tile0; col0 = 16 * b_tile0;
+        a_tile0 = 4 * (wave >> 2); b_tile0 = 2 * (wave & 3); row0 = 32 * a_tile0; col0 = 32 * b_tile0;
     } else if constexpr (KIND == 1) {
-        a_tile0 = 4 * wave; b_tile0 = 0; row0 = 64 * (wave & 3); col0 = 0;
+        a_tile0 = 2 * wave; b_tile0 = 0; row0 = 64 * (wave & 3); col0 = 0;
         if (wave >= 4) { out = task.out2; ldc = task.ldc2; }
     } else if constexpr (KIND == 2) {
-        a_tile0 = 4 * (wave >> 2); b_tile0 = 5 * (wave & 3); row0 = 16 * a_tile0; col0 = 16 * b_tile0;
+        a_tile0 = wave >> 1; b_tile0 = 5 * (wave & 1); row0 = 32 * a_tile0; col0 = 32 * b_tile0;
     } else {
-        a_tile0 = 0; b_tile0 = 2 * wave; row0 = 0; col0 = 32 * wave;
+        a_tile0 = 0; b_tile0 = wave; row0 = 0; col0 = 32 * wave;
         idle = col0 >= task.N;
     }
 
@@ -110,23 +123,37 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         const float* base = task.ld_src[k] ? act : scr;
         gsrc[k] = base + (int64_t)(task.ld_grp[k] + (rgi < task.ld_n[k] ? rgi : 0)) * GROUP_FLOATS + pt * 4;
     }
-    const int wr_off = pt * Im::PS + 8 * rgi;                       // + piece * PL + 256 k
-    // ---- fragment reads: lane 4q+p of group g addresses point 4g+q, rows 4p..4p+3 of a 16-row tile
-    const int rd_off = (4 * g + ((lane >> 2) & 3)) * Im::PS + 8 * (lane & 3);
-    const int rd_a = rd_off + 32 * a_tile0, rd_b = rd_off + 32 * (K::A_TILES + b_tile0);
+    const int wr_off = pt * Im::PS + 8 * swz(rgi, pt);             // + piece * PL + 256 k
+    // ---- fragment reads: in read r (0, 1) lane 4q+p of group g addresses point 8 (g >> 1) + 4 r + q, rows 4p..4p+3 of
+    // the half (g & 1) of a 32-row tile; the lane ends up with rows (lane & 31), k-slots 8 (lane >> 5) + 0..7
+    int rd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int p_ = 8 * (g >> 1) + 4 * r + ((lane >> 2) & 3);
+        rd[r] = p_ * Im::PS + 8 * swz(4 * (g & 1) + (lane & 3), p_);
+    }
+    const int off_a = 64 * a_tile0, off_b = 64 * (K::A_TILES + b_tile0);
+#ifdef DWX_STREAM_ONLY
+    auto frag = [&](const char* img, int off) { bf16x8 z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.0f; return z; };
+#else
+    auto frag = [&](const char* img, int off) { return cat8(tr16(img + rd[0] + off), tr16(img + rd[1] + off)); };
+#endif
 
-    f32x4 stage[NL];
-    auto issue = [&]<int k>(int64_t chunk) {
-        const int64_t off = (chunk >> 3) * tile_floats + (chunk & 7) * (SP * 4);
-        stage[k] = *reinterpret_cast<const f32x4*>(gsrc[k] + off);
+    // ---- loads: two register sets, the stages after next; set (s - c0) & 1 holds stage s
+    f32x4 stage[2][NL];
+    auto request = [&]<int SET, int k>(int64_t chunk) {
+        const int64_t ch = chunk < c1 ? chunk : c1 - 1;          // past the slice: a repeat that nothing uses
+        const int64_t off = (ch >> 3) * tile_floats + (ch & 7) * (SP * 4);
+        stage[SET][k] = *reinterpret_cast<const f32x4*>(gsrc[k] + off);
     };
     float bsum[NBIAS][4];
 #pragma unroll
     for (int k = 0; k < NBIAS; ++k) bsum[k][0] = bsum[k][1] = bsum[k][2] = bsum[k][3] = 0.0f;
     const bool want_bias = task.bias >= 0;
-    // split the four rows of load k and write the pieces into image `img`
-    auto commit = [&]<int k>(char* img, bool count) {
-        const f32x4 v = stage[k];
+    // split the four rows of load k of stage `chunk` into image `img`; count them for the bias if the stage is inside
+    // the slice
+    auto commit = [&]<int SET, int k>(char* img, int64_t chunk) {
+        const f32x4 v = stage[SET][k];
         bf16x4 h, m, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -135,72 +162,81 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
             h[e] = a; m[e] = b; l[e] = c;
         }
         char* dst = img + wr_off + 256 * k;
+#ifdef DWX_STREAM_ONLY
+        asm volatile("" ::"v"(h), "v"(m), "v"(l), "v"(dst));
+#else
         *reinterpret_cast<bf16x4*>(dst) = h;
         *reinterpret_cast<bf16x4*>(dst + Im::PL) = m;
         *reinterpret_cast<bf16x4*>(dst + 2 * Im::PL) = l;
-        if constexpr (k < NBIAS) {
+#endif
+        if constexpr (k < NBIAS) {   // (no branch: the compiler's load bookkeeping stays exact in straight-line code)
+            const float live = chunk < c1 ? 1.0f : 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bsum[k][e] += count ? v[e] : 0.0f;
+            for (int e = 0; e < 4; ++e) bsum[k][e] = fmaf(v[e], live, bsum[k][e]);
         }
     };
 
-    f32x4 acc[TM][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if (c0 < c1) {
-        static_for<NL>([&]<int k>() { issue.template operator()<k>(c0); });
-        static_for<NL>([&]<int k>() { commit.template operator()<k>(smem, true); });
-        static_for<NL>([&]<int k>() { issue.template operator()<k>(c0 + 1 < c1 ? c0 + 1 : c0); });
+        static_for<NL>([&]<int k>() { request.template operator()<0, k>(c0); });
+        static_for<NL>([&]<int k>() { request.template operator()<1, k>(c0 + 1); });
+        static_for<NL>([&]<int k>() {
+            commit.template operator()<0, k>(smem, c0);
+            request.template operator()<0, k>(c0 + 2);
+        });
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    for (int64_t c = c0; c < c1; ++c) {
-        const int buf = (int)((c - c0) & 1);
-        const char* cur = smem + buf * Im::STAGE;
-        char* nxt = smem + (buf ^ 1) * Im::STAGE;
-        const bool more = c + 1 < c1;                    // the registers hold stage c + 1 (or a repeat of the last one)
-        const int64_t c2 = c + 2 < c1 ? c + 2 : c1 - 1;
-
-        // the column fragments of this stage: [hi | hi], [mid | mid], [lo | hi]
-        bf16x8 B1[TN], B2[TN], B3[TN];
+    // one stage; P = (c - c0) & 1 = the image it multiplies from = the register set that holds stage c + 2
+    auto run_stage = [&]<int P>(int64_t c) {
+        const char* cur = smem + P * Im::STAGE;
+        char* nxt = smem + (P ^ 1) * Im::STAGE;
+        bf16x8 B[TN][3];                                 // the column fragments of this stage, pieces hi, mid, lo
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const char* p = cur + rd_b + 32 * j;
-            B1[j] = cat8(tr16(p), tr16(p));
-            B2[j] = cat8(tr16(p + Im::PL), tr16(p + Im::PL));
-            B3[j] = cat8(tr16(p + 2 * Im::PL), tr16(p));
-        }
-        bf16x8 A1[2], A2[2];                             // [hi | mid], [hi | lo] of a row tile, read one tile ahead
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) B[j][s] = frag(cur + s * Im::PL, off_b + 64 * j);
+        bf16x8 A[2][3];                                  // a row tile's fragments, read one tile ahead
         auto read_a = [&]<int i>() {
-            const char* p = cur + rd_a + 32 * i;
-            A1[i & 1] = cat8(tr16(p), tr16(p + Im::PL));
-            A2[i & 1] = cat8(tr16(p), tr16(p + 2 * Im::PL));
+#pragma unroll
+            for (int s = 0; s < 3; ++s) A[i & 1][s] = frag(cur + s * Im::PL, off_a + 64 * i);
         };
         read_a.template operator()<0>();
         static_for<TM>([&]<int i>() {
             if constexpr (i + 1 < TM) read_a.template operator()<i + 1>();
             __builtin_amdgcn_sched_barrier(0);
-            if (!idle) {
+#ifndef DWX_NO_MFMA
+            // (idle waves of a head task multiply too: what they read is finite, and they store nothing)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = mfma16(A1[i & 1], B2[j], acc[i][j]);
-                    acc[i][j] = mfma16(A2[i & 1], B3[j], acc[i][j]);
-                    acc[i][j] = mfma16(A1[i & 1], B1[j], acc[i][j]);
-                }
-            }
-            // staging of stage c + 1 behind the matrix work: load k is split when row tile slot(k) multiplies
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 6; ++q)              // (dY piece, input piece), smallest products first
+                    acc[i][j] = mfma32(A[i & 1][PROD_W[q]], B[j][PROD_X[q]], acc[i][j]);
+#endif
+            // staging of stage c + 1 behind the matrix work: load k is split when row tile group(k) multiplies, and
+            // its registers are re-requested for stage c + 3
             static_for<NL>([&]<int k>() {
                 if constexpr (((k + 1) * TM - 1) / NL == i) {
-                    commit.template operator()<k>(nxt, more);
-                    issue.template operator()<k>(c2);
+                    commit.template operator()<P ^ 1, k>(nxt, c + 1);
+#ifndef DWX_NO_LOAD
+                    request.template operator()<P ^ 1, k>(c + 3);
+#endif
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int64_t c = c0; c < c1; c += 2) {
+        run_stage.template operator()<0>(c);
+        run_stage.template operator()<1>(c + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -211,10 +247,10 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = col0 + 16 * j + (lane & 15);
+                const int col = col0 + 32 * j + (lane & 31);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + 16 * i + 4 * g + r;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < task.M && col < task.N) o[(int64_t)row * ldc + col] = acc[i][j][r];
                 }
             }
@@ -339,7 +375,7 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
     // slab entries no task covers (parameters that receive no gradient) must read as zero in the reduction
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslabs * slab * sizeof(float), stream);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
-    const size_t lds = dwx_lds_bytes(MAX_LOADS);
+    const size_t lds = DWX_LDS_BYTES;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k_dw_x3, dim3(n_wg), dim3(DWX_THREADS), lds, stream, tk, nchunks,
