@@ -439,7 +439,7 @@ def main():
                   "flop_per_point": FLOP_PER_POINT_FWD, "mlp_share_of_step": round(secs / step_secs, 4)})
         return r
 
-    default_kind = "bf16x3" if ops.F32_INFERENCE == "bf16x3" else "mfma32"
+    default_kind = "bf16x3"    # what mlp_dtype = 'f32' (the default) runs
     roofline = mlp_roofline(prof, default_kind, dt)
 
     out = {"metric": "rays/sec per GPU (train step + render) at 64+128 samples; 1/2/4/8 GPU scaling",

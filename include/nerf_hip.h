@@ -114,64 +114,52 @@ int nerf_composite_bwd(int64_t n, int S, const float* raw, const float* z, const
 
 /* ---- the MLP ------------------------------------------------------------------------------ */
 /* The network is NeRF(D=8, W=256, skips=[4]) (run_nerf_helpers.py:73-133) with L=10 / L=4
- * encodings fused in (run_nerf.py:40-66).  Weights are consumed from a packed stream built by
- * nerf_pack_weights from the flat concatenation of the module's parameters in state_dict order. */
+ * encodings fused in (run_nerf.py:40-66).  Weights are consumed from packed streams built from the flat concatenation
+ * of the module's parameters in state_dict order.  One forward and one backward per arithmetic:
+ *   split operands on the bf16 matrix instruction (fp32-accurate, the default):  nerf_mlp_fwd_bf16x3 / nerf_mlp_bwd_bf16x3
+ *   the fp32 matrix instruction:                                                 nerf_mlp_fwd_x4     / nerf_mlp_bwd_x4
+ *   bf16 operands, fp32 sums (inference only, reduced precision):                nerf_mlp_fwd_bf16
+ *   already-encoded inputs, as NeRF.forward(x) receives them upstream:           nerf_mlp_fwd_encoded */
 int64_t nerf_mlp_n_params(int use_viewdirs, int output_ch);   /* floats in the flat parameter vector */
-int64_t nerf_mlp_packed_floats(int use_viewdirs);             /* floats in a forward stream */
-int64_t nerf_mlp_packed_bwd_floats(int use_viewdirs);         /* floats in a backward (transposed) stream */
+int64_t nerf_mlp_packed_floats(int use_viewdirs);             /* floats in the stream of nerf_mlp_fwd_encoded */
 int64_t nerf_mlp_act_floats(int use_viewdirs, int64_t n_pts); /* floats of saved activations for n_pts points */
 int64_t nerf_mlp_scratch_floats(int use_viewdirs, int64_t n_pts); /* floats of backward workspace for n_pts points */
 
-/* Where float `idx` of a packed stream comes from: an index into the flat parameter vector, or -1
- * for a zero.  backward != 0 selects the transposed stream.  Host-only (layout introspection for
- * tests and tools); the _table form fills a HOST array of the stream's length. */
-int64_t nerf_pack_source(int use_viewdirs, int output_ch, int backward, int64_t idx);
-int nerf_pack_source_table(int use_viewdirs, int output_ch, int backward, int64_t* table, int64_t n);
+/* Where float `idx` of the nerf_mlp_fwd_encoded stream comes from: an index into the flat parameter vector, or -1
+ * for a zero.  Host-only (layout introspection for tests and tools); the _table form fills a HOST array of the
+ * stream's length. */
+int64_t nerf_pack_source(int use_viewdirs, int output_ch, int64_t idx);
+int nerf_pack_source_table(int use_viewdirs, int output_ch, int64_t* table, int64_t n);
 
-/* flat params -> forward stream (and, if packed_bwd != NULL, the transposed stream). */
-int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, float* packed_fwd,
-                      float* packed_bwd, void* stream);
-
-/* The same packing as a gather through a precomputed map: nerf_pack_table fills `table` (DEVICE,
- * int32, nerf_mlp_packed_floats + nerf_mlp_packed_bwd_floats entries) once per model shape;
- * nerf_pack_weights_table then repacks in a few microseconds after every optimiser step. */
-int nerf_pack_table(int use_viewdirs, int output_ch, int32_t* table, void* stream);
-int nerf_pack_weights_table(int use_viewdirs, const int32_t* table, const float* params, float* packed_fwd,
-                            float* packed_bwd, void* stream);
+/* flat params -> the stream of nerf_mlp_fwd_encoded. */
+int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, float* packed_fwd, void* stream);
 
 /* out[i] = table[i] < 0 ? 0 : params[table[i]] for i < n (all DEVICE): any packed stream as a gather through a map
- * the caller keeps (e.g. obtained once by packing the vector 1, 2, 3, ... and subtracting one).  Part of the weight
- * hand-over of NeRF.forward (run_nerf_helpers.py:109-133); upstream has no counterpart, its GEMMs read the module's
- * tensors directly. */
+ * the caller keeps (e.g. obtained once by packing the vector 1, 2, 3, ... and subtracting one), a few microseconds
+ * after every optimiser step.  Part of the weight hand-over of NeRF.forward (run_nerf_helpers.py:109-133); upstream has
+ * no counterpart, its GEMMs read the module's tensors directly. */
 int nerf_gather(const int32_t* table, const float* params, float* out, int64_t n, void* stream);
 
-/* NeRF.forward on encoded points (run_nerf_helpers.py:109-133 after run_nerf.py:46-58).
- * pts [n_pts,3]; viewdirs [n_rays,3] (ray of point p = p / pts_per_ray) or NULL when the network
- * has no view branch; out [n_pts, out_ch] (out_ch = 4 with view directions, else output_ch).
- * act: NULL for inference; for training a buffer of nerf_mlp_act_floats() floats receiving the
- * per-layer activations the backward needs. */
-int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
-                 int use_viewdirs, int output_ch, const float* packed_fwd, float* out, float* act,
-                 void* stream);
-
 /* NeRF.forward exactly as upstream calls it (run_nerf_helpers.py:109-133): x [n_pts, 63 (+27)] holds
- * already-encoded inputs (positions, then directions when the network has a view branch). */
+ * already-encoded inputs (positions, then directions when the network has a view branch); out [n_pts, out_ch]
+ * (out_ch = 4 with view directions, else output_ch).  act: NULL for inference; for training a buffer of
+ * nerf_mlp_act_floats() floats receiving the per-layer activations and ReLU mask words the backward passes read. */
 int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int output_ch,
                          const float* packed_fwd, float* out, float* act, void* stream);
 
-/* Inference form of nerf_mlp_fwd on 16-point tiles (v_mfma_f32_16x16x4_f32, two waves per SIMD): the same fp32
- * arithmetic for NeRF.forward under no_grad (run_nerf_helpers.py:109-133 behind run_nerf.py:40-66), same arguments
- * and outputs, `act` as in nerf_mlp_fwd (NULL for inference; otherwise the saved activations and ReLU mask words in
- * the layout nerf_mlp_bwd reads).  packed_x4: nerf_mlp_packed_x4_floats() floats built by nerf_pack_weights_x4
+/* Fused encode + NeRF.forward on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, 16-point tiles, two waves per
+ * SIMD): run_nerf_helpers.py:109-133 behind run_nerf.py:40-66.  pts [n_pts,3]; viewdirs [n_rays,3] (ray of point p =
+ * p / pts_per_ray) or NULL when the network has no view branch; out [n_pts, out_ch]; `act` as in
+ * nerf_mlp_fwd_encoded.  packed_x4: nerf_mlp_packed_x4_floats() floats built by nerf_pack_weights_x4
  * from the flat parameter vector (the module's parameters concatenated in state_dict order). */
 int64_t nerf_mlp_packed_x4_floats(int use_viewdirs);
 int nerf_pack_weights_x4(int use_viewdirs, int output_ch, const float* params, float* packed_x4, void* stream);
 int nerf_mlp_fwd_x4(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                     int use_viewdirs, int output_ch, const float* packed_x4, float* out, float* act, void* stream);
 
-/* bf16-operand / fp32-accumulate inference variant of nerf_mlp_fwd (same arguments and outputs).
+/* bf16-operand / fp32-accumulate inference variant of nerf_mlp_fwd_x4 (same arguments and outputs, no `act`).
  * packed_bf16: nerf_mlp_packed_bf16_bytes() bytes built by nerf_pack_weights_bf16 from the flat
- * parameter vector (the module's parameters concatenated in state_dict order, as for nerf_pack_weights).
+ * parameter vector (the module's parameters concatenated in state_dict order).
  * Every product's inputs are rounded to bf16 (8 significant bits), sums and heads are fp32: raw outputs
  * agree with the fp32 path to about 1e-2 of their scale. */
 int64_t nerf_mlp_packed_bf16_bytes(int use_viewdirs);
@@ -179,9 +167,9 @@ int nerf_pack_weights_bf16(int use_viewdirs, int output_ch, const float* params,
 int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                       int use_viewdirs, int output_ch, const void* packed_bf16, float* out, void* stream);
 
-/* fp32-accurate variant of nerf_mlp_fwd on the bf16 matrix instruction (same arguments and outputs; `act` as in
- * nerf_mlp_fwd_x4: NULL for inference, otherwise the saved activations and mask words nerf_mlp_bwd / _x4 read):
- * every fp32 operand is split exactly into three bf16 pieces and each product is rebuilt from its six largest
+/* fp32-accurate variant of nerf_mlp_fwd_x4 on the bf16 matrix instruction (same arguments and outputs; the default
+ * of the render path and of training): every finite fp32 operand is split exactly into three bf16 pieces (non-finite
+ * and near-overflow values: see NONFINITE below) and each product is rebuilt from its six largest
  * piece products in fp32 accumulators, which measures the same error against fp64 as the fp32 matrix instruction
  * (NeRF.forward, run_nerf_helpers.py:109-133, behind run_nerf.py:40-66).  packed_bf16x3:
  * nerf_mlp_packed_bf16x3_bytes() bytes built by nerf_pack_weights_bf16x3 from the flat parameter vector. */
@@ -190,26 +178,20 @@ int nerf_pack_weights_bf16x3(int use_viewdirs, int output_ch, const float* param
 int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                         int use_viewdirs, int output_ch, const void* packed_bf16x3, float* out, float* act, void* stream);
 
-/* Backward of nerf_mlp_fwd w.r.t. the parameters (inputs carry no gradient upstream:
- * run_nerf.py:467 detaches the samples).  d_out [n_pts,out_ch]; act from the forward;
- * packed_fwd / packed_bwd from nerf_pack_weights; scratch: nerf_mlp_scratch_floats() floats of
- * workspace; d_params: flat gradient, same layout as the flat parameter vector, OVERWRITTEN. */
-int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float* act,
-                 int use_viewdirs, int output_ch, const float* packed_fwd, const float* packed_bwd,
-                 float* scratch, float* d_params, void* stream);
-
-/* nerf_mlp_bwd with its first stage (the gradients of every layer's pre-activations) on 16-point tiles, two waves
- * per SIMD: the mirror of nerf_mlp_fwd_x4, for the same autograd-derived backward of run_nerf_helpers.py:109-133.
- * Same d_out / act / scratch / d_params as nerf_mlp_bwd (act from either forward).  packed_x4: the stream of
+/* Backward of the forward entries w.r.t. the parameters (inputs carry no gradient upstream: run_nerf.py:467 detaches
+ * the samples): what autograd derives for run_nerf_helpers.py:109-133.  d_out [n_pts,out_ch]; act from any forward
+ * above; scratch: nerf_mlp_scratch_floats() floats of workspace; d_params: flat gradient, same layout as the flat
+ * parameter vector, OVERWRITTEN.  Fp32 matrix instruction throughout: backward-data on 16-point tiles (two waves per
+ * SIMD, the mirror of nerf_mlp_fwd_x4), then dW = dY X^T on v_mfma_f32_32x32x2_f32.  packed_x4: the stream of
  * nerf_pack_weights_x4; packed_bwd_x4: nerf_mlp_packed_bwd_x4_floats() floats built by nerf_pack_weights_bwd_x4. */
 int64_t nerf_mlp_packed_bwd_x4_floats(int use_viewdirs);
 int nerf_pack_weights_bwd_x4(int use_viewdirs, int output_ch, const float* params, float* packed_bwd_x4, void* stream);
 int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                     const float* packed_x4, const float* packed_bwd_x4, float* scratch, float* d_params, void* stream);
 
-/* nerf_mlp_bwd with its first stage on the split-operand scheme (the mirror of nerf_mlp_fwd_bf16x3: dY tiles split
- * exactly into three bf16 pieces, W^T as split triples, six piece products, fp32 sums), for the same autograd-derived
- * backward of run_nerf_helpers.py:109-133.  Same d_out / act / scratch / d_params as nerf_mlp_bwd.  packed_bf16x3: the
+/* The same backward on the split-operand scheme, the default (the mirror of nerf_mlp_fwd_bf16x3: dY tiles split
+ * exactly into three bf16 pieces, W^T as split triples, six piece products, fp32 sums, in both stages).  Same d_out /
+ * act / scratch / d_params as nerf_mlp_bwd_x4.  packed_bf16x3: the
  * stream of nerf_pack_weights_bf16x3 (its fp32 tables are read); packed_bwd_bf16x3: nerf_mlp_packed_bwd_bf16x3_bytes()
  * bytes built by nerf_pack_weights_bwd_bf16x3. */
 int64_t nerf_mlp_packed_bwd_bf16x3_bytes(int use_viewdirs);

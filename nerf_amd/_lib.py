@@ -44,15 +44,11 @@ SIGNATURES = {
     "nerf_composite_bwd": (_i, [_l, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_mlp_n_params": (_l, [_i, _i]),
     "nerf_mlp_packed_floats": (_l, [_i]),
-    "nerf_mlp_packed_bwd_floats": (_l, [_i]),
     "nerf_mlp_act_floats": (_l, [_i, _l]),
     "nerf_mlp_scratch_floats": (_l, [_i, _l]),
-    "nerf_pack_source": (_l, [_i, _i, _i, _l]),
-    "nerf_pack_source_table": (_i, [_i, _i, _i, _p, _l]),
-    "nerf_pack_weights": (_i, [_i, _i, _p, _p, _p, _p]),
-    "nerf_pack_table": (_i, [_i, _i, _p, _p]),
-    "nerf_pack_weights_table": (_i, [_i, _p, _p, _p, _p, _p]),
-    "nerf_mlp_fwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "nerf_pack_source": (_l, [_i, _i, _l]),
+    "nerf_pack_source_table": (_i, [_i, _i, _p, _l]),
+    "nerf_pack_weights": (_i, [_i, _i, _p, _p, _p]),
     "nerf_mlp_fwd_encoded": (_i, [_l, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_gather": (_i, [_p, _p, _p, _l, _p]),
     "nerf_mlp_packed_x4_floats": (_l, [_i]),
@@ -74,7 +70,6 @@ SIGNATURES = {
     "nerf_mlp_packed_bf16_bytes": (_l, [_i]),
     "nerf_pack_weights_bf16": (_i, [_i, _i, _p, _p, _p]),
     "nerf_mlp_fwd_bf16": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p]),
-    "nerf_mlp_bwd": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,20 +1,18 @@
-// Backward of the fused MLP w.r.t. its parameters.
+// Backward of the fused MLP w.r.t. its parameters: the entry points, and the weight-gradient stage on the fp32 matrix
+// instruction.
 //
 // Three stages on one stream:
-//  1. k_mlp_bwd_data: dL/d(pre-activation) of every layer.  Same structure as the forward: one
-//     wavefront carries 32 points, gradients live in MFMA accumulator tiles and feed the next
-//     (earlier) layer's W^T product straight from registers; the transposed weights stream through
-//     the LDS slab ring.  ReLU masks are the bit words the forward left behind each tile (16 bytes per lane
-//     and layer instead of a 512-byte re-read of the activations); each layer's dY is written in the blocked layout.                                      Bound: MFMA (9088 per 32 points).
-//  2. k_dw_gemm: dW_l = dY_l * X_l^T, a reduction over points.  Both operands live in the blocked
-//     layout (mlp_layout.hpp): a chunk of 32 points is 512 contiguous bytes per group of four rows,
-//     copied as-is into LDS, where a lane's ds_read_b128 yields four rows of one point = the A (or B)
-//     operands of four different 32x32 output tiles.  One workgroup owns a whole (up to 256x256)
-//     weight tile for one slice of the point range: every operand byte is read from HBM once
-//     (64 FLOP per byte).  The slices per task are chosen so that all workgroups of the launch carry
-//     the same load and fit the chip in one round.  Bias gradients are row sums of the dY operands.
-//  3. k_reduce_slabs: sums the partial slabs in a fixed order (bitwise reproducible, unlike float
-//     atomics).
+//  1. backward-data: dL/d(pre-activation) of every layer, written in the blocked layout of mlp_layout.hpp
+//     (mlp_bwd_bf16x3.hip: split operands on the bf16 matrix instruction, the default; mlp_bwd_x4.hip: fp32 matrix
+//     instruction, for models with mlp_dtype 'f32_mfma').
+//  2. dW_l = dY_l * X_l^T, a reduction over points (mlp_dw_x3.hip for the split-operand path; k_dw_gemm below for the
+//     fp32 one).  k_dw_gemm: both operands live in the blocked layout: a chunk of 32 points is 512 contiguous bytes
+//     per group of four rows, copied as-is into LDS, where a lane's ds_read_b128 yields four rows of one point = the A
+//     (or B) operands of four different 32x32 output tiles.  One workgroup owns a whole (up to 256x256) weight tile for
+//     one slice of the point range: every operand byte is read from HBM once (64 FLOP per byte).  The slices per task
+//     are chosen so that all workgroups of the launch carry the same load and fit the chip in one round.  Bias
+//     gradients are row sums of the dY operands.
+//  3. k_reduce_slabs: sums the partial slabs in a fixed order (bitwise reproducible, unlike float atomics).
 #include "common.hpp"
 #include "mlp_core.hpp"
 #include "mlp_x4.hpp"
@@ -32,152 +30,6 @@ using namespace nerflayout;
 using namespace nerfmlp;
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-// stage 1
-// ------------------------------------------------------------------------------------------------
-// Register tiles <-> blocked layout: `rows` = first row group of the tiles inside this workgroup's tile,
-// lane_off = half * GROUP_FLOATS + 4 * (point in tile); one 16-byte access per register quad.
-template <int NT>
-__device__ __forceinline__ void store_tiles(const f32x16 (&A)[8], float* rows, uint32_t lane_off) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = {A[t][4 * i], A[t][4 * i + 1], A[t][4 * i + 2], A[t][4 * i + 3]};
-            *reinterpret_cast<f32x4*>(rows + (8 * t + 2 * i) * GROUP_FLOATS + lane_off) = v;
-        }
-}
-
-template <bool VIEWDIRS>
-__global__ void __launch_bounds__(THREADS, 1)
-k_mlp_bwd_data(int64_t n_pts, int output_ch, const float* __restrict__ d_out, const float* __restrict__ act,
-               const float* __restrict__ packed_fwd, const float* __restrict__ packed_bwd, float* __restrict__ scr) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ring = smem;
-    float* aux = smem + RING_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int64_t p = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + (lane & 31);
-    const bool valid = p < n_pts;
-    const int pw = wave * 32 + (lane & 31);
-    const uint32_t lane_off = (uint32_t)(h * GROUP_FLOATS + pw * 4);
-    const float* const at = act + (int64_t)blockIdx.x * act_rows(VIEWDIRS ? 1 : 0) * TILE_PTS;   // this workgroup's tiles
-    float* const st_ = scr + (int64_t)blockIdx.x * scr_rows(VIEWDIRS ? 1 : 0) * TILE_PTS;
-    constexpr int SCR_HEAD = scr_head(VIEWDIRS ? 1 : 0), SCR_HEAD2 = SCR_HEAD + 32;
-    auto rows_of = [](auto* tile, int row) { return tile + (row / 4) * GROUP_FLOATS; };
-
-    {
-        const float* gaux = packed_fwd + (int64_t)fwd_stream_blocks(VIEWDIRS ? 1 : 0) * BLOCK_FLOATS;
-        for (int i = tid * 4; i < AUX_FLOATS; i += THREADS * 4)
-            *reinterpret_cast<f32x4*>(aux + i) = *reinterpret_cast<const f32x4*>(gaux + i);
-    }
-    Stream st;
-    st.ring = ring;
-    st.mine = ring + wave * WAVE_BLOCKS * BLOCK_FLOATS;
-    st.g = packed_bwd + wave * WAVE_BLOCKS * BLOCK_FLOATS + lane * 4;
-    st.next = 0;
-    st.nslabs = bwd_stream_blocks(VIEWDIRS ? 1 : 0) / SLAB_BLOCKS;
-    __syncthreads();
-    st.fetch(0);
-
-    // Gradient tiles ping-pong between two arrays: a layer reads one and accumulates W^T dY into the other.
-    f32x16 P[8], Q[8];
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto inP = [&]<int ti>() -> const f32x16& { return P[ti]; };
-    auto inQ = [&]<int ti>() -> const f32x16& { return Q[ti]; };
-    // ReLU mask of masked layer m as the forward left it: bit 16 (t % 2) + r of dword t / 2 <-> register r of tile t.
-    // Requested right before the layer that uses it from its second tile on: the first tile's MFMAs hide the latency.
-    uint32_t mk[4] = {0u, 0u, 0u, 0u};
-    auto load_mask = [&](int m) {
-        const u32x4 w = *reinterpret_cast<const u32x4*>(at + act_mask_offset(VIEWDIRS ? 1 : 0, m, wave, lane));
-        mk[0] = w[0]; mk[1] = w[1]; mk[2] = w[2]; mk[3] = w[3];
-    };
-    auto on = [&](int t, int r) { return ((mk[t >> 1] >> (16 * (t & 1) + r)) & 1u) != 0u; };
-    // A layer's input (the dY of the layer above) goes to the workspace while the layer multiplies: one 16-byte
-    // store behind every other weight block of the second half of each output tile.
-    float* srows = nullptr;
-    auto store_quad = [&]<int T, int I>(const f32x16& a) {
-        const f32x4 v = {a[4 * I], a[4 * I + 1], a[4 * I + 2], a[4 * I + 3]};
-        *reinterpret_cast<f32x4*>(srows + (8 * T + 2 * I) * GROUP_FLOATS + lane_off) = v;
-    };
-    auto saveP = [&]<int TO, int BI>() {
-        if constexpr (BI >= 16 && BI < 24 && (BI & 1) == 0) store_quad.template operator()<TO, (BI - 16) / 2>(P[TO]);
-    };
-    auto saveQ = [&]<int TO, int BI>() {
-        if constexpr (BI >= 16 && BI < 24 && (BI & 1) == 0) store_quad.template operator()<TO, (BI - 16) / 2>(Q[TO]);
-    };
-
-    if constexpr (VIEWDIRS) {
-        f32x4 g = {0, 0, 0, 0};
-        if (valid) g = *reinterpret_cast<const f32x4*>(d_out + p * 4);
-        const float d_sigma = g[3];
-        if (h == 0) {   // head operands of the weight-gradient GEMM: one row group each, zero padded
-            const f32x4 ga = {g[0], g[1], g[2], 0.0f}, gb = {g[3], 0.0f, 0.0f, 0.0f};
-            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD) + pw * 4) = ga;
-            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD2) + pw * 4) = gb;
-        }
-        // views layer: d(hidden) = Wrgb^T d_rgb, masked by the saved post-ReLU activations -> P[0..3]
-        load_mask(8);
-        const float* wrgb = aux + AUX_HEAD + 256;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrgb + t * 32 + h * 16 + 4 * i);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrgb + 128 + t * 32 + h * 16 + 4 * i);
-                const f32x4 w2 = *reinterpret_cast<const f32x4*>(wrgb + 256 + t * 32 + h * 16 + 4 * i);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fmaf(w2[e], g[2], fmaf(w1[e], g[1], w0[e] * g[0]));
-                    P[t][4 * i + e] = on(t, 4 * i + e) ? v : 0.0f;
-                }
-            }
-        // d(feature) = Wviews[:, :256]^T dY_views -> Q; feature_linear has no activation.  Eight output tiles read
-        // four input tiles: two stores of the views dY per output tile.
-        srows = rows_of(st_, SCR_VIEWS);
-        run_layer_bwd<8, 4, false, false>(st, lane, Q, inP, nullptr, 0.0f, mk, [&]<int TO, int BI>() {
-            if constexpr (BI == 8 || BI == 12) store_quad.template operator()<TO / 2, 2 * (TO & 1) + (BI - 8) / 4>(P[TO / 2]);
-        });
-        // d(h7) = Wfeature^T d(feature) + Walpha^T d_sigma, masked -> P
-        load_mask(7);
-        srows = rows_of(st_, SCR_FEAT);
-        run_layer_bwd<8, 8, true, true>(st, lane, P, inQ, aux + AUX_HEAD + h * 16, d_sigma, mk, saveQ);
-    } else {
-        // d(h7) = Wout^T d_out, masked -> P
-        float g[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) g[c] = (valid && c < output_ch) ? d_out[p * output_ch + c] : 0.0f;
-        if (h == 0) {
-            const f32x4 ga = {g[0], g[1], g[2], g[3]}, gb = {g[4], g[5], g[6], g[7]};
-            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD) + pw * 4) = ga;
-            *reinterpret_cast<f32x4*>(rows_of(st_, SCR_HEAD + 4) + pw * 4) = gb;
-        }
-        load_mask(7);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = 0.0f;
-                for (int c = 0; c < output_ch; ++c) v = fmaf(aux[AUX_HEAD + c * 256 + t * 32 + h * 16 + r], g[c], v);
-                P[t][r] = on(t, r) ? v : 0.0f;
-            }
-    }
-
-    // dY of pts layers 6 .. 1, two per trip: P (dY of layer l + 1) -> Q (layer l) -> P (layer l - 1)
-#pragma unroll 1
-    for (int l = 6; l > 0; l -= 2) {
-        load_mask(l);
-        srows = rows_of(st_, SCR_H0 + 256 * (l + 1));
-        run_layer_bwd<8, 8, true, false>(st, lane, Q, inP, nullptr, 0.0f, mk, saveP);
-        load_mask(l - 1);
-        srows = rows_of(st_, SCR_H0 + 256 * l);
-        run_layer_bwd<8, 8, true, false>(st, lane, P, inQ, nullptr, 0.0f, mk, saveQ);
-    }
-    load_mask(0);
-    srows = rows_of(st_, SCR_H0 + 256);
-    run_layer_bwd<8, 8, true, false>(st, lane, Q, inP, nullptr, 0.0f, mk, saveP);
-    store_tiles<8>(Q, rows_of(st_, SCR_H0), lane_off);
-}
 
 // ------------------------------------------------------------------------------------------------
 // stage 2
@@ -563,48 +415,8 @@ extern "C" {
 
 int64_t nerf_mlp_scratch_floats(int use_viewdirs, int64_t n_pts) { return scratch_floats(use_viewdirs, 8, n_pts); }
 
-int nerf_mlp_bwd(int64_t n_pts, int pts_per_ray, const float* d_out, const float* act, int use_viewdirs, int output_ch,
-                 const float* packed_fwd, const float* packed_bwd, float* scratch, float* d_params, void* stream_) {
-    (void)pts_per_ray;
-    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd: n_pts=%lld", (long long)n_pts);
-    NERF_REQUIRE(d_params, "nerf_mlp_bwd: null d_params");
-    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd: output_ch=%d not in 1..8", output_ch);
-    hipStream_t stream = as_stream(stream_);
-    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
-    if (n_pts == 0) {
-        hipError_t e = hipMemsetAsync(d_params, 0, po.total * sizeof(float), stream);
-        return e == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
-    }
-    NERF_REQUIRE(d_out && act && packed_fwd && packed_bwd && scratch, "nerf_mlp_bwd: null pointer");
-    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch) |
-                   reinterpret_cast<uintptr_t>(packed_fwd) | reinterpret_cast<uintptr_t>(packed_bwd)) & 15) == 0,
-                 "nerf_mlp_bwd: buffers must be 16-byte aligned");
-    const int64_t ldp = padded_points(n_pts);
-    const int64_t blocks = ldp / TILE_PTS;
-    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_bwd: n_pts=%lld too large for one call", (long long)n_pts);
-    const int64_t slab = slab_floats(use_viewdirs, output_ch);
-    float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
-    const size_t lds = (RING_FLOATS + AUX_FLOATS) * sizeof(float);
-    hipError_t e;
-    if (use_viewdirs) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_mlp_bwd_data<true>, dim3((unsigned)blocks), dim3(THREADS), lds, stream, n_pts, 4, d_out, act,
-                           packed_fwd, packed_bwd, scratch);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_mlp_bwd_data<false>, dim3((unsigned)blocks), dim3(THREADS), lds, stream, n_pts, output_ch, d_out,
-                           act, packed_fwd, packed_bwd, scratch);
-    }
-    int rc = launched("nerf_mlp_bwd (data)");
-    if (rc) return rc;
-
-    return run_dw(ldp, use_viewdirs, output_ch, po, act, scratch, slabs, slab, d_params, stream);
-}
-
-/* nerf_mlp_bwd with the backward-data stage on 16-point tiles: packed_x4 (tables behind the forward stream) and
- * packed_bwd_x4 (nerf_pack_weights_bwd_x4) in place of the 32-point streams. */
+/* The parameter-gradient pass on the fp32 matrix instruction: backward-data on 16-point tiles, then k_dw_gemm.
+ * packed_x4: the stream of nerf_pack_weights_x4 (its fp32 tables are read); packed_bwd_x4: nerf_pack_weights_bwd_x4. */
 int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                     const float* packed_x4, const float* packed_bwd_x4, float* scratch, float* d_params, void* stream_) {
     NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd_x4: n_pts=%lld", (long long)n_pts);

@@ -159,60 +159,4 @@ __device__ __forceinline__ void run_layer(Stream& st, int lane, f32x16 (&out)[8]
     if constexpr (RELU) static_for<16>([&]<int R>() { relu.template operator()<NOUT - 1, R>(); });
 }
 
-// One backward-data layer on the same ping-pong arrays:
-//     out[to] = keep( start + sum_ti W^T(to, ti) in[ti] )
-// start = 0, or d_sigma times the density head's weight column for the layer that also feeds that head (ALPHA;
-// `alpha_h` = the column in LDS + 16 * lane half); keep (MASK) zeroes every entry whose forward activation was not
-// positive, from the bit words run_layer left behind (same bit layout), as a sign-extended bit ANDed onto the
-// value.  As in the forward pass the start values are written while the previous tile multiplies, a finished tile is
-// masked behind the third block of the next one, and `side` (stores of the layer's INPUT, the previous layer's dY)
-// rides behind the blocks in between; only the last tile's masking is exposed.
-template <int NOUT, int NIN, bool MASK, bool ALPHA, typename InTile, typename Side>
-__device__ __forceinline__ void run_layer_bwd(Stream& st, int lane, f32x16 (&out)[8], InTile in_tile, const float* alpha_h,
-                                              float d_sigma, const uint32_t (&mask)[4], Side side) {
-    constexpr int BPT = NIN * 4, NB = NOUT * BPT, DEPTH = 2;
-    static_assert(BPT >= 8, "a tile spans at least eight blocks");
-    f32x4 abuf[DEPTH + 1];
-    const float* cur = nullptr;
-    auto start = [&]<int TO>() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (ALPHA) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(alpha_h + TO * 32 + 4 * i);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out[TO][4 * i + e] = w[e] * d_sigma;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out[TO][4 * i + e] = 0.0f;
-            }
-        }
-    };
-    auto keep = [&]<int TO, int R>() {
-        if constexpr (MASK) {
-            constexpr int bit = 16 * (TO & 1) + R;
-            const uint32_t m = (uint32_t)((int32_t)(mask[TO >> 1] << (31 - bit)) >> 31);
-            out[TO][R] = __uint_as_float(__float_as_uint(out[TO][R]) & m);
-        }
-    };
-    start.template operator()<0>();
-    static_for<NB + DEPTH>([&]<int I>() {
-        if constexpr (I < NB) {
-            if constexpr (I % SLAB_BLOCKS == 0) cur = st.advance(lane);
-            abuf[I % (DEPTH + 1)] = *reinterpret_cast<const f32x4*>(cur + (I % SLAB_BLOCKS) * BLOCK_FLOATS);
-        }
-        if constexpr (I >= DEPTH) {
-            constexpr int b = I - DEPTH;
-            constexpr int to = b / BPT, bi = b % BPT, ti = bi >> 2, q = bi & 3;
-            const f32x4 a = abuf[b % (DEPTH + 1)];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[to] = mfma(a[e], in_tile.template operator()<ti>()[4 * q + e], out[to]);
-            if constexpr (ti == NIN - 1 && q == 0 && to + 1 < NOUT) start.template operator()<to + 1>();
-            if constexpr (MASK && to > 0 && bi == 2) static_for<16>([&]<int R>() { keep.template operator()<to - 1, R>(); });
-            side.template operator()<to, bi>();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    if constexpr (MASK) static_for<16>([&]<int R>() { keep.template operator()<NOUT - 1, R>(); });
-}
-
 }  // namespace nerfmlp

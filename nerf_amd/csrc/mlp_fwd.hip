@@ -1,4 +1,5 @@
-// Fused positional encoding + NeRF MLP forward on MFMA (fp32 in, fp32 accumulate).
+// NeRF MLP forward on MFMA (fp32 in, fp32 accumulate) for inputs that are ALREADY encoded: NeRF.forward(x) as upstream
+// calls it (run_nerf_helpers.py:109-133).  The render path does not come through here (its kernels fuse the encoding).
 //
 // One workgroup = 4 wavefronts = 128 points; each wavefront carries 32 points through all layers.
 // The activations of a wavefront never leave its registers: the 32x32 accumulator tiles of
@@ -57,9 +58,7 @@ __device__ __forceinline__ float head_dot(const f32x16 (&A)[8], const float* w_l
     return s + __shfl_xor(s, 32, 64);  // the two lane halves hold disjoint feature sets of one point
 }
 
-__device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
-
-template <bool VIEWDIRS, bool SAVE, bool ENCODED>
+template <bool VIEWDIRS, bool SAVE>
 __global__ void __launch_bounds__(THREADS, 1)
 k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
           int output_ch, const float* __restrict__ packed, float* __restrict__ out, float* __restrict__ act) {
@@ -87,7 +86,7 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
 
     // ---- positional encoding into register tiles (slot maps: mlp_layout.hpp)
     f32x16 E[2], D;
-    if constexpr (ENCODED) {
+    {
         // pts is the reference's pre-encoded input [n_pts, 63 (+27)]; pts_per_ray carries its row length
         const float* row = pts + pl * pts_per_ray;
 #pragma unroll
@@ -103,36 +102,6 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
                 const int f = h ? f1 : f0;
                 D[s] = (s >= 14 || (h && f1 < 0)) ? 0.0f : row[IN_PTS + (f < 0 ? 0 : f)];
             }
-        }
-    } else {
-        const float x0 = pts[pl * 3 + 0], x1 = pts[pl * 3 + 1], x2 = pts[pl * 3 + 2];
-        E[0][0] = h ? x2 : x0;
-        E[0][1] = h ? 0.0f : x1;
-#pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            const int c = 15 * h + i, k = c / 3, d = c - 3 * k;
-            const float arg = (d == 0 ? x0 : (d == 1 ? x1 : x2)) * pow2i(k);
-            float sn, cs;
-            sincosf(arg, &sn, &cs);
-            const int s = 2 + 2 * i;
-            if (s < 16) { E[0][s] = sn; E[0][s + 1] = cs; } else { E[1][s - 16] = sn; E[1][s - 15] = cs; }
-        }
-        if (VIEWDIRS) {
-            const int64_t ray = pl / pts_per_ray;
-            const float v0 = viewdirs[ray * 3 + 0], v1 = viewdirs[ray * 3 + 1], v2 = viewdirs[ray * 3 + 2];
-            D[0] = h ? v2 : v0;
-            D[1] = h ? 0.0f : v1;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int c = 6 * h + i, k = c / 3, d = c - 3 * k;
-                const float arg = (d == 0 ? v0 : (d == 1 ? v1 : v2)) * pow2i(k);
-                float sn, cs;
-                sincosf(arg, &sn, &cs);
-                D[2 + 2 * i] = sn;
-                D[3 + 2 * i] = cs;
-            }
-            D[14] = 0.0f;
-            D[15] = 0.0f;
         }
     }
     {
@@ -244,37 +213,18 @@ k_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const f
 }
 
 __global__ void __launch_bounds__(256) k_pack(int use_viewdirs, int output_ch, const float* __restrict__ params,
-                                              float* __restrict__ fwd, int64_t n_fwd, float* __restrict__ bwd,
-                                              int64_t n_bwd) {
-    const int64_t total = n_fwd + n_bwd;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < n_fwd) {
-            const int64_t s = fwd_source(use_viewdirs, output_ch, i);
-            fwd[i] = s < 0 ? 0.0f : params[s];
-        } else {
-            const int64_t s = bwd_source(use_viewdirs, output_ch, i - n_fwd);
-            bwd[i - n_fwd] = s < 0 ? 0.0f : params[s];
-        }
+                                              float* __restrict__ fwd, int64_t n_fwd) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = fwd_source(use_viewdirs, output_ch, i);
+        fwd[i] = s < 0 ? 0.0f : params[s];
     }
 }
 
-// The source map is pure index arithmetic but costs a few hundred instructions per element; training repacks
-// after every optimiser step, so the map is materialised once per model and the repack is a plain gather.
-__global__ void __launch_bounds__(256) k_pack_table(int use_viewdirs, int output_ch, int32_t* __restrict__ table,
-                                                    int64_t n_fwd, int64_t n_bwd) {
-    const int64_t total = n_fwd + n_bwd;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        table[i] = (int32_t)(i < n_fwd ? fwd_source(use_viewdirs, output_ch, i) : bwd_source(use_viewdirs, output_ch, i - n_fwd));
-}
-
-__global__ void __launch_bounds__(256) k_pack_gather(const int32_t* __restrict__ table, const float* __restrict__ params,
-                                                     float* __restrict__ fwd, int64_t n_fwd, float* __restrict__ bwd,
-                                                     int64_t n_bwd) {
-    const int64_t total = n_fwd + n_bwd;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(256) k_gather(const int32_t* __restrict__ table, const float* __restrict__ params,
+                                                float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t s = table[i];
-        const float v = s < 0 ? 0.0f : params[s];
-        if (i < n_fwd) fwd[i] = v; else bwd[i - n_fwd] = v;
+        out[i] = s < 0 ? 0.0f : params[s];
     }
 }
 
@@ -286,79 +236,33 @@ extern "C" {
 
 int64_t nerf_mlp_n_params(int use_viewdirs, int output_ch) { return param_offsets(use_viewdirs, output_ch).total; }
 int64_t nerf_mlp_packed_floats(int use_viewdirs) { return fwd_packed_floats(use_viewdirs); }
-int64_t nerf_mlp_packed_bwd_floats(int use_viewdirs) { return bwd_packed_floats(use_viewdirs); }
 int64_t nerf_mlp_act_floats(int use_viewdirs, int64_t n_pts) { return act_floats(use_viewdirs, n_pts); }
 
-int64_t nerf_pack_source(int use_viewdirs, int output_ch, int backward, int64_t idx) {
-    return backward ? bwd_source(use_viewdirs, output_ch, idx) : fwd_source(use_viewdirs, output_ch, idx);
-}
+int64_t nerf_pack_source(int use_viewdirs, int output_ch, int64_t idx) { return fwd_source(use_viewdirs, output_ch, idx); }
 
-int nerf_pack_source_table(int use_viewdirs, int output_ch, int backward, int64_t* table /* HOST */, int64_t n) {
+int nerf_pack_source_table(int use_viewdirs, int output_ch, int64_t* table /* HOST */, int64_t n) {
     NERF_REQUIRE(table, "nerf_pack_source_table: null pointer");
-    const int64_t want = backward ? bwd_packed_floats(use_viewdirs) : fwd_packed_floats(use_viewdirs);
+    const int64_t want = fwd_packed_floats(use_viewdirs);
     NERF_REQUIRE(n == want, "nerf_pack_source_table: table has %lld entries, stream has %lld", (long long)n, (long long)want);
-    for (int64_t i = 0; i < n; ++i)
-        table[i] = backward ? bwd_source(use_viewdirs, output_ch, i) : fwd_source(use_viewdirs, output_ch, i);
+    for (int64_t i = 0; i < n; ++i) table[i] = fwd_source(use_viewdirs, output_ch, i);
     return 0;
 }
 
-int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, float* packed_fwd, float* packed_bwd,
-                      void* stream) {
+int nerf_pack_weights(int use_viewdirs, int output_ch, const float* params, float* packed_fwd, void* stream) {
     NERF_REQUIRE(params && packed_fwd, "nerf_pack_weights: null pointer");
     NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_pack_weights: output_ch=%d not in 1..8",
                  output_ch);
-    const int64_t nf = fwd_packed_floats(use_viewdirs), nb = packed_bwd ? bwd_packed_floats(use_viewdirs) : 0;
     hipLaunchKernelGGL(k_pack, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, params, packed_fwd,
-                       nf, packed_bwd, nb);
+                       fwd_packed_floats(use_viewdirs));
     return launched("nerf_pack_weights");
-}
-
-int nerf_pack_table(int use_viewdirs, int output_ch, int32_t* table, void* stream) {
-    NERF_REQUIRE(table, "nerf_pack_table: null pointer");
-    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_pack_table: output_ch=%d not in 1..8", output_ch);
-    hipLaunchKernelGGL(k_pack_table, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, table,
-                       fwd_packed_floats(use_viewdirs), bwd_packed_floats(use_viewdirs));
-    return launched("nerf_pack_table");
-}
-
-int nerf_pack_weights_table(int use_viewdirs, const int32_t* table, const float* params, float* packed_fwd,
-                            float* packed_bwd, void* stream) {
-    NERF_REQUIRE(table && params && packed_fwd, "nerf_pack_weights_table: null pointer");
-    const int64_t nf = fwd_packed_floats(use_viewdirs), nb = packed_bwd ? bwd_packed_floats(use_viewdirs) : 0;
-    hipLaunchKernelGGL(k_pack_gather, dim3(1024), dim3(256), 0, as_stream(stream), table, params, packed_fwd, nf, packed_bwd, nb);
-    return launched("nerf_pack_weights_table");
 }
 
 int nerf_gather(const int32_t* table, const float* params, float* out, int64_t n, void* stream) {
     NERF_REQUIRE(n >= 0, "nerf_gather: n=%lld", (long long)n);
     if (n == 0) return 0;
     NERF_REQUIRE(table && params && out, "nerf_gather: null pointer");
-    hipLaunchKernelGGL(k_pack_gather, dim3(1024), dim3(256), 0, as_stream(stream), table, params, out, n, nullptr, (int64_t)0);
+    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, as_stream(stream), table, params, out, n);
     return launched("nerf_gather");
-}
-
-int nerf_mlp_fwd(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
-                 int output_ch, const float* packed_fwd, float* out, float* act, void* stream) {
-    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd: n_pts=%lld", (long long)n_pts);
-    if (n_pts == 0) return 0;
-    NERF_REQUIRE(pts && packed_fwd && out, "nerf_mlp_fwd: null pointer");
-    NERF_REQUIRE(!use_viewdirs || (viewdirs && pts_per_ray >= 1), "nerf_mlp_fwd: view branch needs viewdirs and pts_per_ray >= 1");
-    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_fwd: output_ch=%d not in 1..8", output_ch);
-    NERF_REQUIRE((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
-                 "nerf_mlp_fwd: packed_fwd and out must be 16-byte aligned");
-    const int64_t blocks = (n_pts + TILE_PTS - 1) / TILE_PTS;
-    NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd: n_pts=%lld too large for one launch", (long long)n_pts);
-    NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd: act must be 16-byte aligned");
-    auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)FWD_LDS_BYTES);
-        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), FWD_LDS_BYTES, as_stream(stream), n_pts, ppr, pts,
-                           vd, och, packed_fwd, out, act);
-        return launched("nerf_mlp_fwd");
-    };
-    if (use_viewdirs) return act ? go(k_mlp_fwd<true, true, false>, pts_per_ray, viewdirs, 4) : go(k_mlp_fwd<true, false, false>, pts_per_ray, viewdirs, 4);
-    return act ? go(k_mlp_fwd<false, true, false>, 1, nullptr, output_ch) : go(k_mlp_fwd<false, false, false>, 1, nullptr, output_ch);
 }
 
 int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int output_ch, const float* packed_fwd,
@@ -372,17 +276,16 @@ int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int ou
     const int64_t blocks = (n_pts + TILE_PTS - 1) / TILE_PTS;
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_encoded: n_pts=%lld too large for one launch", (long long)n_pts);
     NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd_encoded: act must be 16-byte aligned");
-    const int ldx = IN_PTS + (use_viewdirs ? IN_DIRS : 0);
+    const int width = IN_PTS + (use_viewdirs ? IN_DIRS : 0);
     auto go = [&](auto kernel, int och) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)FWD_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_encoded: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), FWD_LDS_BYTES, as_stream(stream), n_pts, ldx, x,
-                           (const float*)nullptr, och, packed_fwd, out, act);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), FWD_LDS_BYTES, as_stream(stream), n_pts, width, x,
+                           static_cast<const float*>(nullptr), och, packed_fwd, out, act);
         return launched("nerf_mlp_fwd_encoded");
     };
-    if (use_viewdirs) return act ? go(k_mlp_fwd<true, true, true>, 4) : go(k_mlp_fwd<true, false, true>, 4);
-    return act ? go(k_mlp_fwd<false, true, true>, output_ch) : go(k_mlp_fwd<false, false, true>, output_ch);
+    if (use_viewdirs) return act ? go(k_mlp_fwd<true, true>, 4) : go(k_mlp_fwd<true, false>, 4);
+    return act ? go(k_mlp_fwd<false, true>, output_ch) : go(k_mlp_fwd<false, false>, output_ch);
 }
 
 }  // extern "C"

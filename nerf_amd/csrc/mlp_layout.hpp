@@ -15,7 +15,7 @@
 #pragma once
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NL_HD __host__ __device__
 #else
 #define NL_HD
@@ -183,36 +183,6 @@ NL_HD inline int64_t fwd_source(int use_viewdirs, int output_ch, int64_t idx) {
     a -= output_ch * 256;
     if (a < output_ch) return po.out_b + a;
     return -1;
-}
-
-// ---- backward (transposed) stream ---------------------------------------------------------------
-// dX = W^T dY walks the layers in reverse; the A operand is W^T, i.e. block (to, ti, q) holds
-// W[row = feature of (tile ti, register 4q+e, half)][column = col0 + 32*to + (l&31)].
-// sections: (view branch) views^T [128: 8 out tiles x 4 in tiles] | feature^T [256] |
-//           L7^T, L6^T, L5^T (hidden columns), L4^T .. L1^T [256 each]
-NL_HD inline int bwd_num_sections(int use_viewdirs) { return use_viewdirs ? 9 : 7; }
-NL_HD inline int bwd_section_blocks(int use_viewdirs, int sec) { return (use_viewdirs && sec == 0) ? 128 : 256; }
-NL_HD inline int bwd_stream_blocks(int use_viewdirs) { return use_viewdirs ? 128 + 8 * 256 : 7 * 256; }
-NL_HD inline int64_t bwd_packed_floats(int use_viewdirs) { return (int64_t)bwd_stream_blocks(use_viewdirs) * BLOCK_FLOATS; }
-
-NL_HD inline int64_t bwd_source(int use_viewdirs, int output_ch, int64_t idx) {
-    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
-    int64_t blk = idx / BLOCK_FLOATS;
-    const int within = (int)(idx % BLOCK_FLOATS);
-    const int lane = within >> 2, e = within & 3, h = lane >> 5, col32 = lane & 31;
-    int sec = 0;
-    while (blk >= bwd_section_blocks(use_viewdirs, sec)) { blk -= bwd_section_blocks(use_viewdirs, sec); ++sec; }
-    const int q = (int)(blk & 3), r = 4 * q + e;
-    if (use_viewdirs && sec == 0) {
-        const int ti = (int)((blk >> 2) & 3), to = (int)(blk >> 4);
-        return po.views_w + (int64_t)tile_feature(ti, r, h) * po.views_in + 32 * to + col32;
-    }
-    const int ti = (int)((blk >> 2) & 7), to = (int)(blk >> 5);
-    const int row = tile_feature(ti, r, h), col = 32 * to + col32;
-    if (use_viewdirs && sec == 1) return po.feat_w + (int64_t)row * W + col;
-    const int layer = 7 - (sec - (use_viewdirs ? 2 : 0));   // 7,6,...,1
-    if (layer == 5) return po.pts_w[5] + (int64_t)row * (W + IN_PTS) + IN_PTS + col;
-    return po.pts_w[layer] + (int64_t)row * W + col;
 }
 
 // ---- saved activations (training) --------------------------------------------------------------

@@ -299,52 +299,27 @@ def mlp_n_params(use_viewdirs: bool, output_ch: int) -> int:
     return lib.nerf_mlp_n_params(int(use_viewdirs), output_ch)
 
 
-def pack_table(use_viewdirs: bool, output_ch: int, dev) -> torch.Tensor:
-    """int32 source map of the packed streams (forward entries, then the transposed stream's)."""
-    n = lib.nerf_mlp_packed_floats(int(use_viewdirs)) + lib.nerf_mlp_packed_bwd_floats(int(use_viewdirs))
-    table = torch.empty(n, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        check(lib.nerf_pack_table(int(use_viewdirs), output_ch, table.data_ptr(), _stream()))
-    return table
-
-
-def pack_weights(flat: torch.Tensor, use_viewdirs: bool, output_ch: int, want_bwd: bool, table: Optional[torch.Tensor] = None):
+def pack_weights(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    """flat parameters -> the weight stream of the forward on pre-encoded inputs."""
     flat = _f32c(flat, "params")
     assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
     fwd = torch.empty(lib.nerf_mlp_packed_floats(int(use_viewdirs)), dtype=torch.float32, device=flat.device)
-    bwd = (torch.empty(lib.nerf_mlp_packed_bwd_floats(int(use_viewdirs)), dtype=torch.float32, device=flat.device)
-           if want_bwd else None)
     with torch.cuda.device(flat.device):
-        if table is None:
-            check(lib.nerf_pack_weights(int(use_viewdirs), output_ch, flat.data_ptr(), fwd.data_ptr(), _ptr(bwd), _stream()))
-        else:
-            check(lib.nerf_pack_weights_table(int(use_viewdirs), table.data_ptr(), flat.data_ptr(), fwd.data_ptr(), _ptr(bwd),
-                                              _stream()))
-    return fwd, bwd
+        check(lib.nerf_pack_weights(int(use_viewdirs), output_ch, flat.data_ptr(), fwd.data_ptr(), _stream()))
+    return fwd
 
 
-def mlp_forward(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_fwd: torch.Tensor, use_viewdirs: bool,
-                output_ch: int, pts_per_ray: int, act: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """pts_per_ray > 0: pts are raw positions [P,3] (+ per-ray viewdirs); pts_per_ray == 0: pts are pre-encoded rows."""
-    pts = _f32c(pts, "pts")
-    out_ch = 4 if use_viewdirs else output_ch
-    if pts_per_ray == 0:
-        width = 63 + (27 if use_viewdirs else 0)
-        assert pts.shape[-1] == width, (pts.shape, width)
-        n_pts = pts.numel() // width
-        out = torch.empty((n_pts, out_ch), dtype=torch.float32, device=pts.device)
-        with torch.cuda.device(pts.device):
-            check(lib.nerf_mlp_fwd_encoded(n_pts, pts.data_ptr(), int(use_viewdirs), output_ch, packed_fwd.data_ptr(),
-                                           out.data_ptr(), _ptr(act), _stream()))
-        return out
-    n_pts = pts.numel() // 3
-    out = torch.empty((n_pts, out_ch), dtype=torch.float32, device=pts.device)
-    if use_viewdirs:
-        viewdirs = _f32c(viewdirs, "viewdirs")
-        assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
-    with torch.cuda.device(pts.device), _timed("mlp_fwd" if act is None else "mlp_fwd_save", n_pts):
-        check(lib.nerf_mlp_fwd(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
-                               int(use_viewdirs), output_ch, packed_fwd.data_ptr(), out.data_ptr(), _ptr(act), _stream()))
+def mlp_forward_encoded(x: torch.Tensor, packed_fwd: torch.Tensor, use_viewdirs: bool, output_ch: int,
+                        act: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NeRF.forward on pre-encoded rows [P, 63 (+27)], as upstream calls it."""
+    x = _f32c(x, "x")
+    width = 63 + (27 if use_viewdirs else 0)
+    assert x.shape[-1] == width, (x.shape, width)
+    n_pts = x.numel() // width
+    out = torch.empty((n_pts, 4 if use_viewdirs else output_ch), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.nerf_mlp_fwd_encoded(n_pts, x.data_ptr(), int(use_viewdirs), output_ch, packed_fwd.data_ptr(),
+                                       out.data_ptr(), _ptr(act), _stream()))
     return out
 
 
@@ -366,7 +341,7 @@ def mlp_forward_x4(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed_x
     if use_viewdirs:
         viewdirs = _f32c(viewdirs, "viewdirs")
         assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
-    with torch.cuda.device(pts.device), _timed("mlp_fwd" if act is None else "mlp_fwd_save", n_pts):
+    with torch.cuda.device(pts.device), _timed("mlp_fwd" if act is None else "mlp_fwd_save_f32", n_pts):
         check(lib.nerf_mlp_fwd_x4(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
                                   int(use_viewdirs), output_ch, packed_x4.data_ptr(), out.data_ptr(), _ptr(act), _stream()))
     return out
@@ -424,18 +399,6 @@ def mlp_act_buffer(n_pts: int, use_viewdirs: bool, dev) -> torch.Tensor:
     return torch.empty(lib.nerf_mlp_act_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=dev)
 
 
-def mlp_backward(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_bwd: torch.Tensor,
-                 packed_fwd: torch.Tensor, use_viewdirs: bool, output_ch: int, pts_per_ray: int) -> torch.Tensor:
-    d_out = _f32c(d_out, "d_out")
-    n_pts = d_out.shape[0]
-    scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
-    d_flat = torch.empty_like(flat)
-    with torch.cuda.device(d_out.device), _timed("mlp_bwd", n_pts):
-        check(lib.nerf_mlp_bwd(n_pts, pts_per_ray, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
-                               packed_fwd.data_ptr(), packed_bwd.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(), _stream()))
-    return d_flat
-
-
 def pack_weights_bwd_x4(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
     flat = _f32c(flat, "params")
     assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
@@ -467,23 +430,17 @@ def pack_weights_x4_pair(flat: torch.Tensor, table: torch.Tensor, n_fwd: int):
 
 def mlp_backward_x4(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x4: torch.Tensor,
                     packed_bwd_x4: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
-    """mlp_backward with the backward-data stage on 16-point tiles."""
+    """Parameter gradients on the fp32 matrix instruction (backward-data on 16-point tiles, fp32 weight-gradient GEMM)."""
     d_out = _f32c(d_out, "d_out")
     n_pts = d_out.shape[0]
     scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
     d_flat = torch.empty_like(flat)
-    with torch.cuda.device(d_out.device), _timed("mlp_bwd", n_pts):
+    with torch.cuda.device(d_out.device), _timed("mlp_bwd_f32", n_pts):
         check(lib.nerf_mlp_bwd_x4(n_pts, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
                                   packed_x4.data_ptr(), packed_bwd_x4.data_ptr(), scratch.data_ptr(), d_flat.data_ptr(),
                                   _stream()))
     return d_flat
 
-
-# What a model with mlp_dtype = 'f32' (the default) runs under no_grad: "bf16x3" = the split-operand kernel (fp32
-# accuracy on the bf16 matrix instruction, 1.7x the fp32 matrix instruction's speed), "mfma32" = the fp32 matrix
-# instruction.  mlp_dtype = 'f32_mfma' / 'bf16x3' pick one of the two per model.
-F32_INFERENCE = os.environ.get("NERF_F32_INFERENCE", "bf16x3")
-assert F32_INFERENCE in ("bf16x3", "mfma32"), F32_INFERENCE
 
 def pack_weights_bwd_bf16x3(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
     flat = _f32c(flat, "params")
@@ -496,7 +453,7 @@ def pack_weights_bwd_bf16x3(flat: torch.Tensor, use_viewdirs: bool, output_ch: i
 
 def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x3: torch.Tensor,
                         packed_bwd_x3: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
-    """mlp_backward with the backward-data stage on the split-operand kernel."""
+    """Parameter gradients on the split-operand kernels (backward-data, then the weight-gradient stage)."""
     d_out = _f32c(d_out, "d_out")
     n_pts = d_out.shape[0]
     scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
@@ -511,14 +468,10 @@ def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tens
     return d_flat
 
 
-# backward-data stage on the split-operand kernel (NERF_BWD_X3=0: the fp32 matrix instruction, see BWD_X4)
-BWD_X3 = os.environ.get("NERF_BWD_X3", "1") != "0"
-
-# training forward (with saved activations) on the split-operand kernel (NERF_TRAIN_FWD_X3=0: the fp32 matrix instruction)
-TRAIN_FWD_X3 = os.environ.get("NERF_TRAIN_FWD_X3", "1") != "0"
-
-# backward-data stage on 16-point tiles (NERF_BWD_X4=0 selects the 32-point kernel, kept for A/B runs)
-BWD_X4 = os.environ.get("NERF_BWD_X4", "1") != "0"
+def train_kernels(model) -> str:
+    """Which kernels a training step of `model` runs: 'mfma32' (forward, backward-data and weight gradients on the fp32
+    matrix instruction) for mlp_dtype 'f32_mfma', else 'bf16x3' (all three on the split-operand scheme)."""
+    return "mfma32" if getattr(model, "mlp_dtype", "f32") == "f32_mfma" else "bf16x3"
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -526,41 +479,34 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, viewdirs, model, pts_per_ray, need_grad, *params):
-        x3b = need_grad and BWD_X3
-        x4b = need_grad and BWD_X4 and not x3b
+        kind = train_kernels(model)
         flat = model._flat()
-        fwd = bwd = None
-        if pts_per_ray == 0 or (need_grad and not (x4b or x3b)):
-            fwd, bwd, flat = model._packed(need_grad and not (x4b or x3b))
         n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
-        if pts_per_ray > 0 and need_grad and TRAIN_FWD_X3:   # the split-operand kernel, saving activations
+        if pts_per_ray == 0:      # pre-encoded rows (NeRF.forward(x)); every backward reads what this forward saves
+            out = mlp_forward_encoded(pts, model._packed(), model.use_viewdirs, model.output_ch, act)
+        elif kind == "bf16x3":
             out = mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
-        elif pts_per_ray > 0:   # raw positions: the 16-point-tile kernel (the 32-point one serves pre-encoded inputs)
-            out = mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
         else:
-            out = mlp_forward(pts, viewdirs, fwd, model.use_viewdirs, model.output_ch, pts_per_ray, act)
+            out = mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
         if need_grad:
-            if x3b:   # the streams the backward in use reads, in the slots of the 32-point ones
+            if kind == "bf16x3":
                 fwd, bwd = model._packed_bf16x3(), model._packed_bwd_bf16x3()
-            elif x4b:
+            else:
                 fwd, bwd = model._packed_x4(), model._packed_bwd_x4()
             ctx.save_for_backward(act, fwd, bwd, flat)
-            ctx.x4b, ctx.x3b = x4b, x3b
+            ctx.kind = kind
             ctx.model = model
-            ctx.pts_per_ray = pts_per_ray
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         act, fwd, bwd, flat = ctx.saved_tensors
         model = ctx.model
-        if ctx.x3b:
+        if ctx.kind == "bf16x3":
             d_flat = mlp_backward_bf16x3(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
-        elif ctx.x4b:
-            d_flat = mlp_backward_x4(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
         else:
-            d_flat = mlp_backward(d_out, act, flat, bwd, fwd, model.use_viewdirs, model.output_ch, ctx.pts_per_ray)
+            d_flat = mlp_backward_x4(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
         grads = model._split_flat(d_flat)
         return (None, None, None, None, None) + tuple(grads)
 
@@ -575,7 +521,7 @@ def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_pe
         dtype = getattr(model, "mlp_dtype", "f32")
         if dtype == "bf16":
             return mlp_forward_bf16(pts, viewdirs, model._packed_bf16(), model.use_viewdirs, model.output_ch, pts_per_ray)
-        if dtype == "bf16x3" or (dtype == "f32" and F32_INFERENCE == "bf16x3"):
-            return mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray)
-        return mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray)
+        if dtype == "f32_mfma":
+            return mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray)
+        return mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray)
     return _FusedMLP.apply(pts, viewdirs, model, pts_per_ray, need_grad, *params)

@@ -92,19 +92,20 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(W, output_ch)
         self._pack_key = None
         self._pack = None
-        self._pack_table = None
         self._pack16 = None
         self._packx4 = None
         self._x4_table = None
         self._flat_vec = None
         self._pack16x3 = None
         self._pack16x3b = None
-        # What no-grad queries run (training always runs the fp32 matrix instruction):
-        #   'f32' (default)  fp32 accuracy; the kernel ops.F32_INFERENCE names (the split-operand kernel unless overridden)
-        #   'bf16x3'         fp32 accuracy on the bf16 matrix instruction: operands split exactly into three bf16 pieces,
-        #                    six piece products per product, fp32 sums (same error against fp64 as the fp32 instruction)
-        #   'f32_mfma'       the fp32 matrix instruction
-        #   'bf16'           reduced precision: bf16 operands, fp32 sums, raw outputs within ~1e-2 of their scale
+        # Which kernels evaluate the network:
+        #   'f32' (default)  fp32 accuracy on the bf16 matrix instruction: operands split exactly into three bf16 pieces,
+        #                    six piece products per product, fp32 sums (same error against fp64 as the fp32 instruction);
+        #                    rendering, training forward, backward-data and weight gradients
+        #   'bf16x3'         the same, spelled out
+        #   'f32_mfma'       the fp32 matrix instruction, rendering and all of training
+        #   'bf16'           no-grad queries only, reduced precision: bf16 operands, fp32 sums, raw outputs within ~1e-2
+        #                    of their scale (training with this setting runs the 'f32' kernels)
         self.mlp_dtype = 'f32'
 
     # -- kernel plumbing ---------------------------------------------------------------------------
@@ -144,14 +145,11 @@ class NeRF(nn.Module):
         self._pack_key = None
         self._flat_vec = None
 
-    def _packed(self, want_bwd: bool):
-        """(forward stream, backward stream or None, flat parameters) of the 32-point-tile kernels."""
+    def _packed(self):
+        """Weight stream of the forward on pre-encoded inputs (NeRF.forward(x))."""
         flat = self._flat()
-        if self._pack is None or (want_bwd and self._pack[1] is None):
-            if self._pack_table is None or self._pack_table.device != flat.device:
-                self._pack_table = ops.pack_table(self.use_viewdirs, self.output_ch, flat.device)
-            fwd, bwd = ops.pack_weights(flat, self.use_viewdirs, self.output_ch, want_bwd, self._pack_table)
-            self._pack = (fwd, bwd, flat)
+        if self._pack is None:
+            self._pack = ops.pack_weights(flat, self.use_viewdirs, self.output_ch)
         return self._pack
 
     def _packed_bf16(self):

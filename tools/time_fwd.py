@@ -1,24 +1,33 @@
-"""Times the fp32 inference kernel on one 32768-ray fine chunk (4.19 M points): python tools/time_fwd.py"""
+"""Times the forward kernels on one 32768-ray fine chunk (4.19 M points): python3 tools/time_fwd.py [x3|x4|save] [reps]
+(NERF_HIP_LIB selects a variant build).  x3: the split-operand inference kernel (default); x4: the fp32 matrix
+instruction; save: the split-operand training forward that stores activations (2.1 M points)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from nerf_amd import ops
+which = sys.argv[1] if len(sys.argv) > 1 else "x3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 models, sds, kwargs = bench.build_scene(dev)
 g = torch.Generator(device=dev); g.manual_seed(0)
 m = models[1]
-n_rays, S = 32768, 128
+n_rays, S = (32768, 128) if which != "save" else (16384, 128)
 pts = (torch.rand(n_rays * S, 3, device=dev, generator=g) - 0.5) * 8
 vd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev, generator=g), dim=-1)
-ref = ops.mlp_forward(pts, vd, m._packed(False)[0], True, 5, S)
-out = ops.mlp_forward_x4(pts, vd, m._packed_x4(), True, 5, S)
-print("max diff vs 32-point kernel", (ref - out).abs().max().item())
+act = ops.mlp_act_buffer(n_rays * S, True, dev) if which == "save" else None
+ref = ops.mlp_forward_x4(pts, vd, m._packed_x4(), True, 5, S)
+def run():
+    if which == "x4":
+        return ops.mlp_forward_x4(pts, vd, m._packed_x4(), True, 5, S)
+    return ops.mlp_forward_bf16x3(pts, vd, m._packed_bf16x3(), True, 5, S, act)
+out = run()
+print("max diff vs the fp32 matrix instruction", (ref - out).abs().max().item(), "checksum", float(out.double().sum()))
 for rep in range(3):
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(10):
-        ops.mlp_forward_x4(pts, vd, m._packed_x4(), True, 5, S)
+    for _ in range(reps):
+        run()
     b.record(); torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 10
-    print(f"{ms:.3f} ms, {n_rays * S * 1186816 / ms / 1e9:.1f} TFLOP/s", flush=True)
+    ms = a.elapsed_time(b) / reps
+    print(f"{os.environ.get('NERF_HIP_LIB', 'product')} {which}: {ms:.3f} ms, {n_rays * S * 1186816 / ms / 1e9:.1f} TFLOP/s algorithmic", flush=True)
