@@ -168,10 +168,14 @@ int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const fl
                       int use_viewdirs, int output_ch, const void* packed_bf16, float* out, void* stream);
 
 /* fp32-accurate variant of nerf_mlp_fwd_x4 on the bf16 matrix instruction (same arguments and outputs; the default
- * of the render path and of training): every finite fp32 operand is split exactly into three bf16 pieces (non-finite
- * and near-overflow values: see NONFINITE below) and each product is rebuilt from its six largest
+ * of the render path and of training): every fp32 operand of magnitude below 3.39e38 (the largest bf16) is split exactly
+ * into three bf16 pieces and each product is rebuilt from its six largest
  * piece products in fp32 accumulators, which measures the same error against fp64 as the fp32 matrix instruction
- * (NeRF.forward, run_nerf_helpers.py:109-133, behind run_nerf.py:40-66).  packed_bf16x3:
+ * (NeRF.forward, run_nerf_helpers.py:109-133, behind run_nerf.py:40-66).  Non-finite values: an infinite or NaN operand
+ * splits into pieces that contain a NaN, so the result is NaN (upstream: NaN as well as soon as the infinity meets
+ * weights of both signs, which the next layer's sum does); a finite operand of magnitude 3.39e38 or more also gives
+ * NaN where the fp32 instruction stays finite.  The ReLU of all MLP kernels keeps a NaN a NaN, like torch.relu.
+ * packed_bf16x3:
  * nerf_mlp_packed_bf16x3_bytes() bytes built by nerf_pack_weights_bf16x3 from the flat parameter vector. */
 int64_t nerf_mlp_packed_bf16x3_bytes(int use_viewdirs);
 int nerf_pack_weights_bf16x3(int use_viewdirs, int output_ch, const float* params, void* packed_bf16x3, void* stream);

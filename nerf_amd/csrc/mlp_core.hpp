@@ -46,6 +46,10 @@ struct Stream {
     }
 };
 
+// max(v, lo) that keeps a NaN a NaN, as torch.relu does (fmaxf would return the other operand and turn a NaN
+// pre-activation into 0); one v_maximum3_f32, where fmaxf costs a canonicalising v_max_f32 more
+__device__ __forceinline__ float max_keep_nan(float v, float lo) { return __builtin_elementwise_maximum(v, lo); }
+
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -128,7 +132,7 @@ __device__ __forceinline__ void run_layer(Stream& st, int lane, f32x16 (&out)[8]
         }
     };
     auto relu = [&]<int TO, int R>() {
-        const float y = fmaxf(out[TO][R], 0.0f);
+        const float y = max_keep_nan(out[TO][R], 0.0f);
         out[TO][R] = y;
         if constexpr (MASK) {   // y >= 0, so "positive" = "bits != 0"
             const uint32_t one = __float_as_uint(y) < 1u ? __float_as_uint(y) : 1u;

@@ -115,8 +115,8 @@ __device__ __forceinline__ void layer16(Stream16& st, int lane, int g, const cha
             v0 += bb[0];
             v1 += bb[1];
         }
-        v0 = fmaxf(v0, lo);
-        v1 = fmaxf(v1, lo);
+        v0 = max_keep_nan(v0, lo);
+        v1 = max_keep_nan(v1, lo);
 #pragma unroll
         for (int k = 0; k < NHEAD; ++k) {
             const f32x2 w = *reinterpret_cast<const f32x2*>(hp + k * head_stride + 16 * TP + 2 * pr);

@@ -72,7 +72,7 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
         constexpr int ct = K >> 2, r = K & 3;
         float v = acc[TP & 1][ct][r];
         if constexpr (!BIAS_INIT) v += bp[16 * TP + r];
-        v = fmaxf(v, lo);
+        v = max_keep_nan(v, lo);
 #pragma unroll
         for (int k = 0; k < NHEAD; ++k) {
             head[ct][k] = fmaf(v, hp[k * head_stride + 16 * TP + r], head[ct][k]);

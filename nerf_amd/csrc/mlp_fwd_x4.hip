@@ -98,7 +98,7 @@ __device__ __forceinline__ void layer_x4(StreamX4& st, int lane, const float*& c
             if constexpr (RELU) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float y = fmaxf(out[t][i], 0.0f);
+                    const float y = max_keep_nan(out[t][i], 0.0f);
                     out[t][i] = y;
                     if constexpr (MASK) {   // y >= 0, so "positive" = "bits != 0"
                         const uint32_t one = __float_as_uint(y) < 1u ? __float_as_uint(y) : 1u;

@@ -104,10 +104,11 @@ def render_sharded(H: int, W: int, K, chunk: int, rays, render_fn: Optional[Call
 
 
 def render_path_sharded(render_poses, hwf, K, chunk: int, render_kwargs, render_factor: int = 0,
-                        render_fn: Optional[Callable] = None, group=None):
+                        render_fn: Optional[Callable] = None, group=None, savedir: Optional[str] = None):
     """The pose loop of render_path (run_nerf.py:163-201) with the FRAMES dealt round-robin to the ranks: rank r
     renders poses r, r + world, ...; one all_gather of the finished frames returns the whole sequence, in pose
-    order, on every rank as (rgbs [N,H,W,3], disps [N,H,W]) tensors."""
+    order, on every rank as (rgbs [N,H,W,3], disps [N,H,W]) tensors.  With savedir every rank writes the PNGs of its
+    own frames ('{pose index:03d}.png'), each copied to the host and encoded while the rank's next frame renders."""
     if render_fn is None:
         from .run_nerf import render as render_fn
     rank, world = _world(group)
@@ -118,9 +119,25 @@ def render_path_sharded(render_poses, hwf, K, chunk: int, render_kwargs, render_
     n = len(render_poses)
     per = (n + world - 1) // world
     mine = []
+    frames, pending = None, None
+    if savedir is not None:
+        from .run_nerf import FrameDownloader, _write_png
+        from .run_nerf_helpers import to8b
+        frames = FrameDownloader()
+
+        def write(i, handle):
+            (rgb8,) = frames.finish(handle)
+            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgb8))
     for i in range(rank, n, world):
         rgb, disp, _, _ = render_fn(H, W, K, chunk=chunk, c2w=render_poses[i][:3, :4], **render_kwargs)
         mine.append(torch.cat([rgb.reshape(H, W, 3), disp.reshape(H, W, 1)], -1))
+        if frames is not None:
+            handle = frames.start(rgb.reshape(H, W, 3))
+            if pending is not None:
+                write(*pending)
+            pending = (i, handle)
+    if pending is not None:
+        write(*pending)
     dev, dtype = (mine[0].device, mine[0].dtype) if mine else (None, torch.float32)
     if world == 1:
         frames = torch.stack(mine, 0)

@@ -96,8 +96,54 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     return ret_list + [ret_dict]
 
 
+class FrameDownloader:
+    """Finished frames -> host arrays without stalling the stream that renders the next frame.
+
+    start(*tensors) records an event on the current stream, lets a side stream wait for it and copy the tensors into
+    one of two sets of pinned host buffers; finish(handle) waits for that copy alone and returns numpy copies.  Used
+    as start(frame i); finish(frame i-1): the device-to-host copy of a frame and its 8-bit conversion / PNG encoding on
+    the host overlap the rendering of the next one, and the host never synchronises the render stream (upstream's
+    `.cpu()` per frame, run_nerf.py:181-182, does).  CPU tensors pass straight through."""
+
+    def __init__(self, slots: int = 2):
+        self.slots = [None] * slots
+        self.count = 0
+        self.side = None
+
+    def start(self, *tensors):
+        if not tensors[0].is_cuda:
+            return ("host", [t.detach().numpy().copy() for t in tensors])
+        dev = tensors[0].device
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        slot = self.count % len(self.slots)
+        self.count += 1
+        host = self.slots[slot]
+        if host is None or any(h.shape != t.shape or h.dtype != t.dtype for h, t in zip(host, tensors)):
+            host = self.slots[slot] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        self.side.wait_event(ready)
+        with torch.cuda.stream(self.side):
+            for h, t in zip(host, tensors):
+                h.copy_(t.detach(), non_blocking=True)
+                t.record_stream(self.side)       # the allocator must not hand the frame's memory out before the copy ran
+            done = torch.cuda.Event()
+            done.record(self.side)
+        return ("pinned", slot, done)
+
+    def finish(self, handle):
+        if handle[0] == "host":
+            return handle[1]
+        _, slot, done = handle
+        done.synchronize()
+        return [h.numpy().copy() for h in self.slots[slot]]
+
+
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
-    """run_nerf.py:163-201.  Frames are written as PNG with PIL when savedir is given."""
+    """run_nerf.py:163-201: one render() per pose, frames returned as numpy arrays and written as PNG (PIL) when savedir
+    is given.  As upstream, render_factor shrinks H, W and the focal of `hwf` but K is passed on unchanged.  Frame i is
+    copied to the host and encoded while frame i+1 renders (FrameDownloader)."""
     H, W, focal = hwf
     if render_factor != 0:
         H = H // render_factor
@@ -105,17 +151,29 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         focal = focal / render_factor
 
     rgbs, disps = [], []
+    frames = FrameDownloader()
+
+    def collect(i, handle):
+        rgb, disp = frames.finish(handle)
+        rgbs.append(rgb)
+        disps.append(disp)
+        if i == 0:
+            print(rgb.shape, disp.shape)
+        if savedir is not None:
+            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgb))  # noqa: F405
+
     t = time.time()
+    pending = None
     for i, c2w in enumerate(render_poses):
         print(i, time.time() - t)
         t = time.time()
         rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
-        if i == 0:
-            print(rgb.shape, disp.shape)
-        if savedir is not None:
-            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))  # noqa: F405
+        handle = frames.start(rgb, disp)
+        if pending is not None:
+            collect(*pending)
+        pending = (i, handle)
+    if pending is not None:
+        collect(*pending)
     return np.stack(rgbs, 0), np.stack(disps, 0)
 
 
@@ -384,12 +442,9 @@ def _render_frames(rank, world, render_poses, hwf, K, chunk, render_kwargs, gt_i
     if world == 1:
         return render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=gt_imgs, savedir=savedir,
                            render_factor=render_factor)
-    rgbs, disps = parallel.render_path_sharded(render_poses, hwf, K, chunk, render_kwargs, render_factor=render_factor)
-    rgbs, disps = rgbs.cpu().numpy(), disps.cpu().numpy()
-    if rank == 0 and savedir is not None:
-        for k, frame in enumerate(rgbs):
-            _write_png(os.path.join(savedir, '{:03d}.png'.format(k)), to8b(frame))  # noqa: F405
-    return rgbs, disps
+    rgbs, disps = parallel.render_path_sharded(render_poses, hwf, K, chunk, render_kwargs, render_factor=render_factor,
+                                               savedir=savedir)   # every rank writes the PNGs of its own frames
+    return rgbs.cpu().numpy(), disps.cpu().numpy()
 
 
 def load_dataset(args):

@@ -1,0 +1,147 @@
+"""Parity cases at the edges of the render path: frames through render_path (render_factor, 8-bit conversion, PNG files),
+per-ray near/far bounds, non-finite and huge activations in the split-operand kernel, weights written behind autograd's
+back.  Same oracle and tolerances as test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from test_gpu_parity import T, _model, _peaky, _query_fn, close, exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(device, n_coarse=16, n_fine=16):
+    sd_c, sd_f = _peaky(O.random_state_dict(71), 25.0), _peaky(O.random_state_dict(72), 25.0)
+    kw = dict(network_fn=_model(sd_c, device), network_fine=_model(sd_f, device), network_query_fn=_query_fn(),
+              N_samples=n_coarse, N_importance=n_fine, perturb=0.0, raw_noise_std=0.0, white_bkgd=True, use_viewdirs=True,
+              ndc=False, near=2.0, far=6.0)
+    return sd_c, sd_f, kw
+
+
+def test_render_path_frames_match_the_oracle(device, tmp_path):
+    """render_path (run_nerf.py:163-201) on three poses, whole and with render_factor=2: every frame against the oracle
+    render of the same pose (as upstream, the factor shrinks H, W and hwf's focal while K is passed on unchanged), the
+    8-bit frames against to8b of the oracle's, the PNG files against the returned frames, pose order kept."""
+    from PIL import Image
+    from nerf_amd.run_nerf import render_path
+    from nerf_amd.run_nerf_helpers import to8b
+    sd_c, sd_f, kw = _scene(device)
+    H, W, focal = 20, 24, 30.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    poses = torch.stack([O.orbit_pose(th, -30.0, 4.0) for th in (-120.0, 10.0, 95.0)], 0)
+    for factor in (0, 2):
+        out = tmp_path / f"f{factor}"
+        os.makedirs(out)
+        with torch.no_grad():
+            rgbs, disps = render_path(poses.to(device), [H, W, focal], K, 100, kw, savedir=str(out), render_factor=factor)
+        h, w = (H, W) if factor == 0 else (H // factor, W // factor)
+        assert rgbs.shape == (3, h, w, 3) and disps.shape == (3, h, w) and rgbs.dtype == np.float32
+        assert sorted(os.listdir(out)) == ["000.png", "001.png", "002.png"]
+        for i in range(3):
+            o, d = O.pixel_rays(h, w, K, poses[i, :3, :4])
+            with torch.no_grad():
+                want = O.render_chunks(O.pack_rays(o, d, 2.0, 6.0, use_viewdirs=True), 1 << 15, sd_coarse=sd_c, sd_fine=sd_f,
+                                       n_coarse=16, n_fine=16, white_bkgd=True)
+            close(rgbs[i].reshape(-1, 3), want["rgb_map"], 2e-4, 2e-5, f"frame {i} rgb (factor {factor})")
+            close(disps[i].reshape(-1), want["disp_map"], 1e-3, 1e-5, f"frame {i} disp (factor {factor})")
+            got8, want8 = to8b(rgbs[i]), to8b(want["rgb_map"].numpy().reshape(h, w, 3))
+            diff = np.abs(got8.astype(np.int32) - want8.astype(np.int32))
+            # truncation to 8 bits turns a 1e-6 difference into one count where 255 x sits on an integer
+            assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
+            png = np.asarray(Image.open(out / f"{i:03d}.png"))
+            assert np.array_equal(png, got8), f"PNG {i} is the 8-bit frame"
+        # frames differ from each other (pose order is observable) and the sequence is deterministic
+        assert np.abs(rgbs[0] - rgbs[1]).max() > 1e-3
+        with torch.no_grad():
+            again, _ = render_path(poses.to(device), [H, W, focal], K, 100, kw, render_factor=factor)
+        assert np.array_equal(again, rgbs)
+
+
+def test_per_ray_bounds(device):
+    """near / far that differ from ray to ray: through the ray record builder (bit-exact columns) and through
+    render_rays against the oracle's march on the same records."""
+    from nerf_amd import ops
+    from nerf_amd.run_nerf import render_rays
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 77
+    o = T(rng.normal(size=(n, 3)).astype(np.float32) * 0.3 + np.array([0, 0, 4.0], dtype=np.float32))
+    d = T(rng.normal(size=(n, 3)).astype(np.float32) * 0.2 + np.array([0, 0, -1.0], dtype=np.float32))
+    near = T(rng.uniform(1.0, 2.5, size=(n,)).astype(np.float32))
+    far = T(rng.uniform(5.0, 7.0, size=(n,)).astype(np.float32))
+    rec = ops.pack_rays(o.to(device), d.to(device), near.to(device), far.to(device), viewdir_src=d.to(device))
+    want = O.pack_rays(o, d, 0.0, 0.0, use_viewdirs=True)
+    want[:, 6], want[:, 7] = near, far
+    exact(rec[:, :8], want[:, :8], "ray records with per-ray bounds: origins, directions, bounds")
+    close(rec[:, 8:], want[:, 8:], 0, 1.2e-7, "unit view directions (the CPU norm sums in another order)")
+    # one bound per ray, the other a scalar; 8-column records
+    rec8 = ops.pack_rays(o.to(device), d.to(device), 2.0, far.to(device))
+    exact(rec8[:, 6], torch.full((n,), 2.0), "scalar near")
+    exact(rec8[:, 7], far, "per-ray far")
+    sd_c, sd_f, kw = _scene(device)
+    for k in ("ndc", "near", "far", "use_viewdirs"):
+        kw.pop(k)
+    with torch.no_grad():
+        got = render_rays(rec, **kw)
+        ref = O.march(want, sd_c, sd_f, 16, 16, white_bkgd=True)
+    close(got["rgb_map"], ref["rgb_map"], 2e-4, 2e-5, "rgb with per-ray bounds")
+    close(got["acc_map"], ref["acc_map"], 2e-4, 2e-5, "acc with per-ray bounds")
+    close(got["z_std"], ref["z_std"], 1e-4, 1e-6, "z_std with per-ray bounds")
+
+
+def test_split_operand_kernel_on_huge_and_non_finite_activations(device):
+    """One hidden unit of layer 0 is driven to 1e30, to +inf and to NaN through its bias.  Huge finite activations: the
+    split-operand kernel agrees with the fp32 matrix instruction to the usual relative tolerance.  Non-finite ones: the
+    reference's ReLU keeps a NaN a NaN, an infinite unit meets weights of both signs in the next layer (inf - inf), so
+    upstream returns NaN at every point and channel; so do both kernels (an infinite operand splits into inf, NaN, NaN:
+    the split scheme reaches NaN one layer earlier than the fp32 instruction, never a finite number)."""
+    from nerf_amd import ops
+    rng = np.random.Generator(np.random.PCG64(6))
+    n, s = 40, 8
+    pts = T(rng.uniform(-2, 2, size=(n * s, 3)).astype(np.float32))
+    vd = T(rng.normal(size=(n, 3)).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+
+    def both(bias_value):
+        sd = O.random_state_dict(81)
+        sd["pts_linears.0.bias"][7] = bias_value
+        m = _model(sd, device)
+        with torch.no_grad():
+            a = ops.mlp_forward_bf16x3(pts.to(device), vd.to(device), m._packed_bf16x3(), True, 5, s)
+            b = ops.mlp_forward_x4(pts.to(device), vd.to(device), m._packed_x4(), True, 5, s)
+            want = O.query_field(pts.reshape(n, s, 3), vd, sd).reshape(-1, 4)
+        return a.cpu().numpy(), b.cpu().numpy(), want.numpy()
+
+    a, b, want = both(1e30)
+    assert np.isfinite(a).all() and np.isfinite(b).all() and np.abs(b).max() > 1e20
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(a, b, rtol=0, atol=3e-6 * scale)
+    np.testing.assert_allclose(a, want, rtol=0, atol=2e-5 * scale)
+    for bad in (float("inf"), float("nan")):
+        a, b, want = both(bad)
+        assert np.isnan(want).all(), "upstream arithmetic gives NaN everywhere"
+        assert np.isnan(b).all(), "fp32 matrix instruction"
+        assert np.isnan(a).all(), "split operands"
+
+
+def test_weights_written_through_data_need_invalidate_packs(device):
+    """The packed weight streams follow in-place parameter updates that autograd sees (optimiser steps); a write through
+    `.data` is invisible to that bookkeeping until invalidate_packs() is called."""
+    qf = _query_fn()
+    m = _model(O.random_state_dict(91), device)
+    rng = np.random.Generator(np.random.PCG64(7))
+    pts = T(rng.uniform(-2, 2, size=(6, 4, 3)).astype(np.float32)).to(device)
+    vd = torch.nn.functional.normalize(T(rng.normal(size=(6, 3)).astype(np.float32)), dim=-1).to(device)
+    with torch.no_grad():
+        before = qf(pts, vd, m).clone()
+        m.rgb_linear.weight.mul_(2.0)                    # bumps the version counter: picked up by itself
+        visible = qf(pts, vd, m).clone()
+        m.rgb_linear.weight.data.mul_(0.5)               # back to the start, behind the counter's back
+        stale = qf(pts, vd, m).clone()
+        m.invalidate_packs()
+        fresh = qf(pts, vd, m).clone()
+    assert float((visible - before).abs().max()) > 0
+    exact(stale, visible, "a .data write alone leaves the packed streams as they were")
+    close(fresh, before, 0, 1e-6, "after invalidate_packs the streams follow the parameters")

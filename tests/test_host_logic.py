@@ -162,3 +162,21 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_get_rays_np_matches_reference_outputs():
+    """The product's float64 start-up rays (run_nerf_helpers.py:217-226) against the reference's own outputs."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import golden
+    from nerf_amd.run_nerf_helpers import get_rays_np
+    g = golden("rays")
+    for name in ("lego_half", "lego_full", "fern"):
+        H, W, focal = g[name + "_hwf"]
+        H, W = int(H), int(W)
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        pose = g[name + "_pose"]
+        o, d = get_rays_np(H, W, K, pose)
+        assert d.dtype == np.float64 and d.shape == (H, W, 3) and o.shape == (H, W, 3)
+        assert np.array_equal(d.reshape(-1, 3)[g[name + "_pick"]], g[name + "_d_np"]), name
+        assert np.array_equal(o[0, 0], pose[:3, -1]) and np.array_equal(o[-1, -1], pose[:3, -1])

@@ -69,17 +69,41 @@ def _fake_frame(H, W, K, chunk, c2w, **kw):
     return [torch.stack([base, base * 2, base * 3], -1), base * 0.5, None, {}]
 
 
-def _frames(rank, world):
+def _frames(rank, world, savedir=None):
     from nerf_amd.parallel import render_path_sharded
     ok = True
     for n in (5, 1, 4):          # more, fewer and as many frames as a multiple of the ranks
         poses = torch.zeros(n, 4, 4)
         poses[:, 0, 3] = torch.arange(n, dtype=torch.float32) * 100.0
-        rgbs, disps = render_path_sharded(poses, [6, 8, 10.0], None, 16, {}, render_factor=2, render_fn=_fake_frame)
+        sub = None if savedir is None else os.path.join(savedir, str(n))
+        if sub is not None:
+            os.makedirs(sub, exist_ok=True)
+        rgbs, disps = render_path_sharded(poses, [6, 8, 10.0], None, 16, {}, render_factor=2, render_fn=_fake_frame, savedir=sub)
         want = [_fake_frame(3, 4, None, 16, poses[i]) for i in range(n)]
         ok = ok and rgbs.shape == (n, 3, 4, 3) and disps.shape == (n, 3, 4)
         ok = ok and all(torch.equal(rgbs[i], want[i][0]) and torch.equal(disps[i], want[i][1]) for i in range(n))
     return bool(ok)
+
+
+def _frames_saved(rank, world):
+    return _frames(rank, world, savedir=os.environ["NERF_TEST_FRAMES_DIR"])
+
+
+def test_render_path_sharded_writes_every_frame_once_in_pose_order(tmp_path, monkeypatch):
+    """Each rank writes the PNGs of the frames it rendered; together they are the whole sequence, named by pose."""
+    from PIL import Image
+    from nerf_amd.run_nerf_helpers import to8b
+    monkeypatch.setenv("NERF_TEST_FRAMES_DIR", str(tmp_path))
+    assert _run(_frames_saved) == [True, True]
+    for n in (5, 1, 4):
+        names = sorted(os.listdir(tmp_path / str(n)))
+        assert names == ['{:03d}.png'.format(i) for i in range(n)]
+        for i in range(n):
+            pose = torch.zeros(4, 4)
+            pose[0, 3] = 100.0 * i
+            want = to8b(_fake_frame(3, 4, None, 16, pose)[0].numpy())
+            got = np.asarray(Image.open(tmp_path / str(n) / '{:03d}.png'.format(i)))
+            assert np.array_equal(got, want), (n, i)
 
 
 def test_render_path_sharded_returns_frames_in_pose_order():
