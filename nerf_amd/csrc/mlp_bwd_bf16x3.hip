@@ -83,6 +83,11 @@ __device__ __forceinline__ void layer_x3b(Stream3& st, int lane, int g, const ch
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
             if constexpr (I % SLABT == 0) cur = st.advance(lane);
+#ifdef X3_SPREAD   // one request of the slab after next behind each of the first six triples of a slab
+            if constexpr (I % SLABT >= 1 && I % SLABT <= WAVE_BLOCKS3) {
+                if (st.next + 1 < st.nslabs) st.template fetch_block<I % SLABT - 1>(st.next + 1);
+            }
+#endif
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 abuf[I % (DEPTH + 1)][s] = *reinterpret_cast<const bf16x8*>(cur + (I % SLABT) * TRIPLE_BYTES + s * 1024);

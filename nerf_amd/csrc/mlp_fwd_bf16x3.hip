@@ -70,6 +70,9 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
     auto load_bias = [&]<int TO>() { bnext = *reinterpret_cast<const f32x4*>(bp + 16 * TO); };
     auto piece = [&]<int TP, int K>() {           // K = 4 * column tile + register: one value of the tile per piece
         constexpr int ct = K >> 2, r = K & 3;
+#ifdef X3_NO_EPI
+        if constexpr (NHEAD == 0 && !SAVE) return;
+#endif
         float v = acc[TP & 1][ct][r];
         if constexpr (!BIAS_INIT) v += bp[16 * TP + r];
         v = max_keep_nan(v, lo);
@@ -98,6 +101,14 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
             if constexpr (I % SLABT == 0) cur = st.advance(lane);
+#ifdef X3_SPREAD   // one request of the slab after next behind each of the first six triples of a slab
+            if constexpr (I % SLABT >= 1 && I % SLABT <= WAVE_BLOCKS3) {
+                if (st.next + 1 < st.nslabs) st.template fetch_block<I % SLABT - 1>(st.next + 1);
+            }
+#endif
+#ifdef X3_NO_AREAD
+            if constexpr (I < DEPTH + 1)
+#endif
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 abuf[I % (DEPTH + 1)][s] = *reinterpret_cast<const bf16x8*>(cur + (I % SLABT) * TRIPLE_BYTES + s * 1024);
