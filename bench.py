@@ -189,7 +189,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     graphed: the same step recorded into HIP graphs after three eager steps and replayed (nerf_amd.graph_step)."""
     from nerf_amd import ops, parallel
     from nerf_amd.run_nerf import render
-    from nerf_amd.run_nerf_helpers import get_rays, img2mse
+    from nerf_amd.run_nerf_helpers import img2mse
     H = W = 400
     K = lego_camera(H, W)
     kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
@@ -203,7 +203,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     pts_per_ray = 2 * kw["N_samples"] + kw["N_importance"]
     params = list(models[0].parameters()) + list(models[1].parameters())
     saved = [p.detach().clone() for p in params]
-    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=graphed)
+    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=graphed, fused=True)   # as create_nerf
     stepper = None
     if graphed:
         from nerf_amd.graph_step import GraphedTrainStep
@@ -214,17 +214,19 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     thetas = np.linspace(-180, 180, 41)[:-1]
-    poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(max(warmup, 5) + steps)]
+    n_views = 8
+    poses = torch.stack([orbit_pose(thetas[(5 * i) % 40]) for i in range(n_views)], 0)
     if scene == "fern":   # cameras at z ~ 0 looking down -z, shifted sideways along a line
-        poses = [torch.tensor([[1., 0, 0, 0.2 * np.sin(0.7 * i)], [0, 1., 0, 0.1 * np.cos(0.7 * i)], [0, 0, 1., 0.05 * i % 0.3]],
-                              dtype=torch.float32, device=dev) for i in range(len(poses))]
-    target_img = torch.rand(H * W, 3, device=dev, generator=gen)
+        poses = torch.tensor([[[1., 0, 0, 0.2 * np.sin(0.7 * i)], [0, 1., 0, 0.1 * np.cos(0.7 * i)], [0, 0, 1., 0.05 * i % 0.3]]
+                              for i in range(n_views)], dtype=torch.float32)
+    images = torch.rand(n_views, H, W, 3, device=dev, generator=gen)
+    # the package's own no_batching sampler (run_nerf.py:833-854): one view per step, N_rand distinct pixels of it,
+    # rays and target colours of exactly those pixels from one kernel
+    from nerf_amd.raybatch import ViewSampler
+    sampler = ViewSampler(images, poses, list(range(n_views)), H, W, K, n_rand, device=dev, seed=seed)
 
     def one(i):
-        rays_o, rays_d = get_rays(H, W, K, poses[i])
-        sel = torch.randperm(H * W, device=dev, generator=gen)[:n_rand]
-        batch_rays = torch.stack([rays_o.reshape(-1, 3)[sel], rays_d.reshape(-1, 3)[sel]], 0)
-        target = target_img[sel]
+        batch_rays, target = sampler.next(i, img_i=i % n_views)
         if stepper is not None:
             stepper.set_lr(5e-4 * (0.1 ** (i / (500 * 1000))))
             return stepper.step(batch_rays, target)

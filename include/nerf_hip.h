@@ -53,6 +53,15 @@ int nerf_rays_at(int64_t n, const int64_t* pick, int H, int W, int row0, int col
                  float fy, float cx, float cy, const float* c2w, const float* image, float* rays_o, float* rays_d,
                  float* target, void* stream);
 
+/* nerf_rays_at with the n DISTINCT pixels of the window drawn inside the kernel: pixel k is P(k) for a permutation P of
+ * [0, win_rows*win_cols) keyed by `seed` (a four-round Feistel network walked back into the range), so one launch
+ * replaces the reference's np.random.choice(..., replace=False) + gather (run_nerf.py:848-851); the choice is
+ * pseudo-random and reproducible from the seed, it is not numpy's stream.  pick_out (optional, [n]): the pixels drawn,
+ * numbered like nerf_rays_at's pick.  n must not exceed the window's pixel count. */
+int nerf_rays_random(int64_t n, uint64_t seed, int H, int W, int row0, int col0, int win_rows, int win_cols, float fx,
+                     float fy, float cx, float cy, const float* c2w, const float* image, float* rays_o, float* rays_d,
+                     float* target, int64_t* pick_out, void* stream);
+
 /* ndc_rays (run_nerf_helpers.py:230-255) on n rays; sx = -1/(W/(2 focal)), sy = -1/(H/(2 focal))
  * evaluated in double by the caller and rounded to fp32, as the upstream scalar arithmetic does.
  * In-place use (o_out == o_in, d_out == d_in) is allowed. */
@@ -202,6 +211,18 @@ int64_t nerf_mlp_packed_bwd_bf16x3_bytes(int use_viewdirs);
 int nerf_pack_weights_bwd_bf16x3(int use_viewdirs, int output_ch, const float* params, void* packed_bwd_bf16x3, void* stream);
 int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                         const void* packed_bf16x3, const void* packed_bwd_bf16x3, float* scratch, float* d_params, void* stream);
+
+/* Both split streams in one launch, as a gather through an int32 map the caller keeps (all DEVICE).  `out` receives
+ * triples0 triples (3 KiB each: 512 bf16 hi | 512 mid | 512 lo), then n_aux fp32 values (a multiple of 4), then
+ * triples1 triples; `table` holds, in that order, 512 entries per triple and one per fp32 value: the index into
+ * params of the value to split (or copy), or -1 for a zero.  With the map obtained once per model by running
+ * nerf_pack_weights_bf16x3 and nerf_pack_weights_bwd_bf16x3 on the vector 1, 2, 3, ... and summing the pieces,
+ * out = the first stream followed by the second, rebuilt in a few microseconds after every optimiser step.
+ * nerf_mlp_bf16x3_triples(): triples in the forward stream (the rest of its bytes are the fp32 tables).  Part of the
+ * weight hand-over of NeRF.forward (run_nerf_helpers.py:109-133); upstream has no counterpart. */
+int64_t nerf_mlp_bf16x3_triples(int use_viewdirs);
+int nerf_gather_split3(const int32_t* table, const float* params, void* out, int64_t triples0, int64_t n_aux,
+                       int64_t triples1, void* stream);
 
 /* The two stages of nerf_mlp_bwd_bf16x3 as separate calls (same arguments; the stages communicate through `scratch`
  * only, so a caller can time them, or overlap other work between them): _data fills the dY rows of every layer

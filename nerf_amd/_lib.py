@@ -34,6 +34,7 @@ SIGNATURES = {
     "nerf_check_device": (_i, []),
     "nerf_get_rays": (_i, [_i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
     "nerf_rays_at": (_i, [_l, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "nerf_rays_random": (_i, [_l, ctypes.c_uint64, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_ndc_rays": (_i, [_l, _f, _f, _f, _p, _p, _p, _p, _p]),
     "nerf_pack_rays": (_i, [_l, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _p]),
     "nerf_sample_coarse": (_i, [_l, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "nerf_mlp_packed_bwd_bf16x3_bytes": (_l, [_i]),
     "nerf_pack_weights_bwd_bf16x3": (_i, [_i, _i, _p, _p, _p]),
     "nerf_mlp_bwd_bf16x3": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "nerf_mlp_bf16x3_triples": (_l, [_i]),
+    "nerf_gather_split3": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "nerf_mlp_bwd_data_bf16x3": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_mlp_bwd_weights_bf16x3": (_i, [_l, _p, _i, _i, _p, _p, _p]),
     "nerf_mlp_bwd_static_max_points": (_l, []),

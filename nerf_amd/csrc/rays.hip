@@ -56,6 +56,57 @@ __global__ void __launch_bounds__(256) k_rays_at(int64_t n, const int64_t* __res
     }
 }
 
+// Distinct pseudo-random pixels without a sort: k -> P(k), k < n, where P is a keyed permutation of [0, n_pix) -- a
+// four-round Feistel network on the 2h-bit numbers (4^h >= n_pix > 4^(h-1)), walked along its cycle until the value
+// is inside the range again (a permutation of the larger set restricted this way is a permutation of the smaller one;
+// under four tries on average).  Stands in for np.random.choice(n_pix, n, replace=False) of run_nerf.py:848.
+struct PickKey {
+    uint32_t k[4];
+    int h;
+};
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint64_t keyed_pixel(uint64_t k, uint64_t n_pix, const PickKey& key) {
+    const uint32_t mask = (1u << key.h) - 1u;
+    uint64_t x = k;
+    do {
+        uint32_t l = (uint32_t)(x >> key.h) & mask, r = (uint32_t)x & mask;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            const uint32_t f = mix32(r * 0x9e3779b1u + key.k[round]) & mask;
+            const uint32_t t = l ^ f;
+            l = r;
+            r = t;
+        }
+        x = ((uint64_t)l << key.h) | r;
+    } while (x >= n_pix);
+    return x;
+}
+
+// k_rays_at with the pixels drawn inside the kernel (keyed_pixel); pick_out (optional) receives them.
+__global__ void __launch_bounds__(256) k_rays_random(int64_t n, PickKey key, int64_t n_pix, int W, int row0, int col0,
+                                                     int win_cols, float fx, float fy, float cx, float cy,
+                                                     const float* __restrict__ c2w, const float* __restrict__ image,
+                                                     float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                     float* __restrict__ target, int64_t* __restrict__ pick_out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * 3; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / 3;
+        const int r = (int)(e - k * 3);
+        const int64_t q = (int64_t)keyed_pixel((uint64_t)k, (uint64_t)n_pix, key);
+        if (pick_out && r == 0) pick_out[k] = q;
+        const int j = row0 + (int)(q / win_cols), i = col0 + (int)(q % win_cols);
+        const float dx = ((float)i - cx) / fx;
+        const float dy = -(((float)j - cy) / fy);
+        const float dz = -1.0f;
+        const float m0 = c2w[r * 4 + 0], m1 = c2w[r * 4 + 1], m2 = c2w[r * 4 + 2];
+        rays_d[e] = (dx * m0 + dy * m1) + dz * m2;
+        rays_o[e] = c2w[r * 4 + 3];
+        if (image) target[e] = image[((int64_t)j * W + i) * 3 + r];
+    }
+}
+
 // run_nerf_helpers.py:230-255.
 __global__ void __launch_bounds__(256) k_ndc(int64_t n, float sx, float sy, float near, const float* o_in,
                                              const float* d_in, float* o_out, float* d_out) {
@@ -197,6 +248,36 @@ int nerf_rays_at(int64_t n, const int64_t* pick, int H, int W, int row0, int col
     hipLaunchKernelGGL(k_rays_at, dim3(grid_for(n * 3)), dim3(256), 0, as_stream(stream), n, pick, W, row0, col0, win_cols,
                        fx, fy, cx, cy, c2w, image, rays_o, rays_d, target);
     return launched("nerf_rays_at");
+}
+
+int nerf_rays_random(int64_t n, uint64_t seed, int H, int W, int row0, int col0, int win_rows, int win_cols, float fx,
+                     float fy, float cx, float cy, const float* c2w, const float* image, float* rays_o, float* rays_d,
+                     float* target, int64_t* pick_out, void* stream) {
+    NERF_REQUIRE(n >= 0, "nerf_rays_random: n=%lld", (long long)n);
+    NERF_REQUIRE(H > 0 && W > 0 && win_rows > 0 && win_cols > 0 && row0 >= 0 && col0 >= 0 && row0 + win_rows <= H &&
+                 col0 + win_cols <= W, "nerf_rays_random: window %dx%d at (%d,%d) does not fit a %dx%d image", win_rows,
+                 win_cols, row0, col0, H, W);
+    const int64_t n_pix = (int64_t)win_rows * win_cols;
+    NERF_REQUIRE(n <= n_pix, "nerf_rays_random: %lld distinct pixels asked of a window of %lld", (long long)n, (long long)n_pix);
+    NERF_REQUIRE(fx != 0.0f && fy != 0.0f, "nerf_rays_random: zero focal length");
+    if (n == 0) return 0;
+    NERF_REQUIRE(c2w && rays_o && rays_d, "nerf_rays_random: null pointer");
+    NERF_REQUIRE(!image || target, "nerf_rays_random: image given without a target buffer");
+    PickKey key;
+    key.h = 1;
+    while (((int64_t)1 << (2 * key.h)) < n_pix) ++key.h;        // 4^h >= n_pix, h <= 31
+    NERF_REQUIRE(key.h <= 31, "nerf_rays_random: window too large");
+    uint64_t sm = seed;
+    for (int r = 0; r < 4; ++r) {                                // splitmix64: four round keys out of the seed
+        sm += 0x9e3779b97f4a7c15ull;
+        uint64_t z = sm;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        key.k[r] = (uint32_t)((z ^ (z >> 31)) >> 16);
+    }
+    hipLaunchKernelGGL(k_rays_random, dim3(grid_for(n * 3)), dim3(256), 0, as_stream(stream), n, key, n_pix, W, row0, col0,
+                       win_cols, fx, fy, cx, cy, c2w, image, rays_o, rays_d, target, pick_out);
+    return launched("nerf_rays_random");
 }
 
 int nerf_ndc_rays(int64_t n, float sx, float sy, float near, const float* o_in, const float* d_in, float* o_out,

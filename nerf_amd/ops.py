@@ -105,6 +105,27 @@ def rays_at(pick: torch.Tensor, H: int, W: int, window, fx: float, fy: float, cx
     return o, d, target
 
 
+def rays_random(n: int, seed: int, H: int, W: int, window, fx: float, fy: float, cx: float, cy: float, c2w: torch.Tensor,
+                image: Optional[torch.Tensor] = None, want_pick: bool = False):
+    """Rays (and target colours) of n distinct pseudo-random pixels of a window (row0, col0, rows, cols) of one view,
+    drawn inside the kernel from `seed` -> rays [2, n, 3] (origins, directions), target, pick (None unless asked for)."""
+    c2w = _f32c(to_dev(c2w)[:3, :4], "c2w")
+    n = int(n)
+    row0, col0, rows, cols = [int(v) for v in window]
+    both = torch.empty((2, n, 3), dtype=torch.float32, device=c2w.device)
+    o, d = both[0], both[1]
+    target = None
+    if image is not None:
+        image = _f32c(image, "image")
+        assert image.numel() == H * W * 3, (image.shape, H, W)
+        target = torch.empty_like(o)
+    pick = torch.empty((n,), dtype=torch.int64, device=c2w.device) if want_pick else None
+    with torch.cuda.device(c2w.device), _timed("rays_random", n * (24 + (24 if image is not None else 0))):
+        check(lib.nerf_rays_random(n, int(seed) & 0xffffffffffffffff, H, W, row0, col0, rows, cols, fx, fy, cx, cy,
+                                   c2w.data_ptr(), _ptr(image), o.data_ptr(), d.data_ptr(), _ptr(target), _ptr(pick), _stream()))
+    return both, target, pick
+
+
 def ndc_rays(sx: float, sy: float, near: float, rays_o: torch.Tensor, rays_d: torch.Tensor):
     o, d = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d")
     oo, od = torch.empty_like(o), torch.empty_like(d)
@@ -253,12 +274,16 @@ class _Composite(torch.autograd.Function):
                                          weights.data_ptr(), depth.data_ptr(), _stream()))
         ctx.save_for_backward(raw, z, rays, noise, weights)
         ctx.white = bool(white_bkgd)
+        # outputs the loss does not touch arrive as None in backward (not as zero tensors the kernel would have to read)
+        ctx.set_materialize_grads(False)
         return rgb, disp, acc, weights, depth
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_weights, g_depth):
         raw, z, rays, noise, weights = ctx.saved_tensors
         n, S = z.shape
+        if all(t is None for t in (g_rgb, g_disp, g_acc, g_weights, g_depth)):
+            return None, None, None, None, None
         d_raw = torch.empty_like(raw)
 
         def g(t):
@@ -451,6 +476,35 @@ def pack_weights_bwd_bf16x3(flat: torch.Tensor, use_viewdirs: bool, output_ch: i
     return out
 
 
+def x3_pack_table(use_viewdirs: bool, output_ch: int, dev):
+    """(int32 source map of the forward split stream, its fp32 tables and the transposed split stream; triples in the
+    first; fp32 table entries; triples in the second): the packing kernels run once on the vector 1, 2, 3, ... -- the
+    three pieces of a split add up to the value exactly, and a network has under 2^24 parameters."""
+    n = mlp_n_params(use_viewdirs, output_ch)
+    assert n < (1 << 24)
+    ramp = torch.arange(1, n + 1, dtype=torch.float32, device=dev)
+    a = pack_weights_bf16x3(ramp, use_viewdirs, output_ch)
+    b = pack_weights_bwd_bf16x3(ramp, use_viewdirs, output_ch)
+    t0 = lib.nerf_mlp_bf16x3_triples(int(use_viewdirs))
+    assert (a.numel() - t0 * 3072) % 16 == 0 and b.numel() % 3072 == 0
+    n_aux, t1 = (a.numel() - t0 * 3072) // 4, b.numel() // 3072
+
+    def triples(raw, t):
+        return raw[:t * 3072].view(torch.bfloat16).reshape(t, 3, 512).float().sum(1).reshape(-1)
+    src = torch.cat([triples(a, t0), a[t0 * 3072:].view(torch.float32), triples(b, t1)])
+    return (src.to(torch.int32) - 1).contiguous(), t0, n_aux, t1
+
+
+def pack_weights_x3_pair(flat: torch.Tensor, table: torch.Tensor, t0: int, n_aux: int, t1: int):
+    """-> (forward split stream with its fp32 tables, transposed split stream): one gather-and-split launch."""
+    flat = _f32c(flat, "params")
+    n0 = t0 * 3072 + n_aux * 4
+    out = torch.empty(n0 + t1 * 3072, dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_gather_split3(table.data_ptr(), flat.data_ptr(), out.data_ptr(), t0, n_aux, t1, _stream()))
+    return out[:n0], out[n0:]
+
+
 def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x3: torch.Tensor,
                         packed_bwd_x3: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
     """Parameter gradients on the split-operand kernels (backward-data, then the weight-gradient stage)."""
@@ -486,7 +540,8 @@ class _FusedMLP(torch.autograd.Function):
         if pts_per_ray == 0:      # pre-encoded rows (NeRF.forward(x)); every backward reads what this forward saves
             out = mlp_forward_encoded(pts, model._packed(), model.use_viewdirs, model.output_ch, act)
         elif kind == "bf16x3":
-            out = mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
+            out = mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(with_bwd=need_grad), model.use_viewdirs, model.output_ch,
+                                     pts_per_ray, act)
         else:
             out = mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
         if need_grad:

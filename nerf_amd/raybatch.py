@@ -66,8 +66,6 @@ class ViewSampler:
         self.i_train = np.asarray(i_train)
         self.H, self.W, self.K = int(H), int(W), K
         self.N_rand, self.precrop_iters, self.precrop_frac = int(N_rand), int(precrop_iters), float(precrop_frac)
-        self.gen = torch.Generator(device=dev)
-        self.gen.manual_seed(int(seed))
         self.host_rng = np.random.RandomState(int(seed))
         self.dev = dev
 
@@ -88,8 +86,10 @@ class ViewSampler:
         n_pix = win[2] * win[3]
         if self.N_rand > n_pix:
             raise ValueError(f"N_rand={self.N_rand} exceeds the {n_pix} pixels of the sampling window")
-        pick = torch.randperm(n_pix, device=self.dev, generator=self.gen)[:self.N_rand]   # distinct pixels
         K = self.K
-        o, d, target = ops.rays_at(pick, self.H, self.W, win, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
-                                   self.poses[img_i], self.images[img_i])
-        return torch.stack([o, d], 0), target
+        # distinct pixels from a keyed permutation evaluated inside the ray kernel (one launch; a device randperm of
+        # the window is a sort of a dozen launches); the key comes from this sampler's host generator
+        seed = int(self.host_rng.randint(0, 2 ** 31 - 1)) * (2 ** 31) + int(self.host_rng.randint(0, 2 ** 31 - 1))
+        rays, target, _ = ops.rays_random(self.N_rand, seed, self.H, self.W, win, float(K[0][0]), float(K[1][1]),
+                                          float(K[0][2]), float(K[1][2]), self.poses[img_i], self.images[img_i])
+        return rays, target

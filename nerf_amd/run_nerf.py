@@ -59,7 +59,8 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
             if k not in all_ret:
                 all_ret[k] = []
             all_ret[k].append(ret[k])
-    all_ret = {k: torch.cat(all_ret[k], 0) for k in all_ret}
+    # (a single chunk -- every training batch -- is returned as it is: concatenating one tensor is a copy per key)
+    all_ret = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
     return all_ret
 
 
@@ -202,7 +203,8 @@ def create_nerf(args):
                                                                         embeddirs_fn=embeddirs_fn,
                                                                         netchunk=args.netchunk)
 
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    # (fused: the same Adam as one multi-tensor launch per step instead of seven)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), fused=True)
 
     start = 0
     basedir = args.basedir

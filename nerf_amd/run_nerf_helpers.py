@@ -9,7 +9,8 @@ import torch.nn as nn
 from . import ops
 
 # Misc (run_nerf_helpers.py:8-10) -- the train-step tail stays in PyTorch.
-img2mse = lambda x, y: torch.mean((x - y) ** 2)
+# (img2mse: mean((x - y) ** 2) as the library's fused mse_loss -- two launches forward and backward instead of eight)
+img2mse = lambda x, y: torch.nn.functional.mse_loss(x, y)
 mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
 
@@ -62,6 +63,21 @@ def get_embedder(multires, i=0):
 # ------------------------------------------------------------------------------------------------
 # Model (run_nerf_helpers.py:73-133)
 # ------------------------------------------------------------------------------------------------
+# Every optimiser step in the process advances this count; the packed weight streams are keyed on it as well as on the
+# parameters' version counters, because fused optimiser kernels (torch.optim.Adam(..., fused=True)) update the
+# parameters without touching those counters.
+_OPT_STEPS = [0]
+
+
+def _count_optimizer_step(optimizer, args, kwargs):
+    _OPT_STEPS[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_count_optimizer_step)
+
+
 class NeRF(nn.Module):
     """Same constructor, attributes and state_dict as upstream; forward runs the fused MFMA kernel.
 
@@ -95,7 +111,9 @@ class NeRF(nn.Module):
         self._pack16 = None
         self._packx4 = None
         self._x4_table = None
+        self._x3_table = None
         self._flat_vec = None
+        self._flat_addrs = ()
         self._pack16x3 = None
         self._pack16x3b = None
         # Which kernels evaluate the network:
@@ -123,27 +141,39 @@ class NeRF(nn.Module):
                 "implements D=8, W=256, skips=[4], input_ch=63 and input_ch_views=27 (or 0 without view directions)")
 
     def _flat(self) -> torch.Tensor:
-        """The parameters as one flat vector (state_dict order); every packed stream is dropped when a parameter
-        changed (in-place updates bump the tensors' version counters)."""
+        """The parameters as one flat vector (state_dict order).  On first use the module ADOPTS one flat buffer: every
+        parameter's `.data` becomes a view into it (same values, shapes, names and state_dict), so that optimiser steps
+        and load_state_dict write the vector the kernels' weight streams are packed from and no per-step concatenation
+        is needed.  A parameter whose storage was replaced since (`.to()`, `p.data = ...`) is noticed by its address and
+        the buffer is rebuilt from the current values.  Every packed stream is dropped when a parameter changed
+        (in-place updates bump the tensors' version counters)."""
         self._check_arch()
         params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._flat_vec is None or self._pack_key != key:
+        store = self._flat_vec
+        if store is None or any(p.data_ptr() != a for p, a in zip(params, self._flat_addrs)):
             with torch.no_grad():
-                flat = torch.cat([p.detach().reshape(-1) for p in params])
-            if not flat.is_cuda:
+                store = torch.cat([p.detach().reshape(-1) for p in params])
+            if not store.is_cuda:
                 raise RuntimeError("NeRF parameters must live on a HIP device (call .to('cuda'))")
-            self._flat_vec, self._pack_key = flat, key
+            off, addrs = 0, []
+            for p in params:
+                n = p.numel()
+                p.data = store[off:off + n].view(p.shape)
+                addrs.append(p.data_ptr())
+                off += n
+            self._flat_vec, self._flat_addrs, self._pack_key = store, addrs, None
+        key = (_OPT_STEPS[0],) + tuple(p._version for p in params)
+        if self._pack_key != key:
+            self._pack_key = key
             self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = None
-        return self._flat_vec
+        return store
 
     def invalidate_packs(self) -> None:
         """Forget every packed weight stream; the next query rebuilds them from the parameters.  The cache key is each
-        parameter's (address, version counter), which in-place autograd-visible updates bump; writes that bypass the
-        counter -- `p.data.copy_(...)`, `p.data.mul_(...)`, a HIP-graph replay of an optimiser step, an external loader
+        parameter's version counter, which in-place autograd-visible updates bump, and the number of optimiser steps taken
+        in the process; writes that bypass both -- `p.data.copy_(...)`, `p.data.mul_(...)`, a HIP-graph replay of an optimiser step, an external loader
         writing through data_ptr() -- must be followed by this call."""
         self._pack_key = None
-        self._flat_vec = None
 
     def _packed(self):
         """Weight stream of the forward on pre-encoded inputs (NeRF.forward(x))."""
@@ -158,17 +188,28 @@ class NeRF(nn.Module):
             self._pack16 = ops.pack_weights_bf16(flat, self.use_viewdirs, self.output_ch)
         return self._pack16
 
-    def _packed_bf16x3(self):
+    def _packed_bf16x3(self, with_bwd: bool = False):
+        """Forward split stream.  with_bwd (a training step): it comes together with the transposed one out of one
+        gather-and-split launch through a map built once; otherwise the forward stream is packed alone."""
         flat = self._flat()
         if self._pack16x3 is None:
-            self._pack16x3 = ops.pack_weights_bf16x3(flat, self.use_viewdirs, self.output_ch)
+            if with_bwd:
+                self._packed_x3_pair()
+            else:
+                self._pack16x3 = ops.pack_weights_bf16x3(flat, self.use_viewdirs, self.output_ch)
         return self._pack16x3
 
     def _packed_bwd_bf16x3(self):
-        flat = self._flat()
+        self._flat()
         if self._pack16x3b is None:
-            self._pack16x3b = ops.pack_weights_bwd_bf16x3(flat, self.use_viewdirs, self.output_ch)
+            self._packed_x3_pair()
         return self._pack16x3b
+
+    def _packed_x3_pair(self):
+        flat = self._flat()
+        if self._x3_table is None or self._x3_table[0].device != flat.device:
+            self._x3_table = ops.x3_pack_table(self.use_viewdirs, self.output_ch, flat.device)
+        self._pack16x3, self._pack16x3b = ops.pack_weights_x3_pair(flat, *self._x3_table)
 
     def _packed_x4_pair(self):
         """(forward stream, transposed stream) of the 16-point-tile kernels: one gather through a map built once."""

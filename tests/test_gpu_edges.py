@@ -145,3 +145,65 @@ def test_weights_written_through_data_need_invalidate_packs(device):
     assert float((visible - before).abs().max()) > 0
     exact(stale, visible, "a .data write alone leaves the packed streams as they were")
     close(fresh, before, 0, 1e-6, "after invalidate_packs the streams follow the parameters")
+
+
+@pytest.mark.parametrize("use_viewdirs,output_ch", [(True, 5), (False, 4), (False, 5)])
+def test_split_streams_from_one_gather_equal_the_packing_kernels(device, use_viewdirs, output_ch):
+    """nerf_gather_split3 through the map taken from the packing kernels rebuilds both split streams (and the forward
+    stream's fp32 tables) bit for bit, on ordinary weights and on values whose pieces carry signs and zeros."""
+    from nerf_amd import ops
+    n = ops.mlp_n_params(use_viewdirs, output_ch)
+    table = ops.x3_pack_table(use_viewdirs, output_ch, device)
+    rng = np.random.Generator(np.random.PCG64(3))
+    for scale in (1.0, 1e-3, 1e4):
+        flat = T((rng.standard_normal(n) * scale).astype(np.float32)).to(device)
+        flat[::7] = 0.0
+        flat[1::11] = -flat[1::11].abs()
+        a, b = ops.pack_weights_x3_pair(flat, *table)
+        exact(a, ops.pack_weights_bf16x3(flat, use_viewdirs, output_ch), "forward split stream")
+        exact(b, ops.pack_weights_bwd_bf16x3(flat, use_viewdirs, output_ch), "transposed split stream")
+
+
+def test_parameters_live_in_one_flat_buffer(device):
+    """After the first query the parameters are views of one flat vector: names, shapes and values unchanged, optimiser
+    steps and load_state_dict land in the vector the weight streams are packed from, and a parameter whose storage
+    was replaced is adopted again with its new values."""
+    qf = _query_fn()
+    sd = O.random_state_dict(93)
+    m = _model(sd, device)
+    rng = np.random.Generator(np.random.PCG64(8))
+    pts = T(rng.uniform(-2, 2, size=(5, 4, 3)).astype(np.float32)).to(device)
+    vd = torch.nn.functional.normalize(T(rng.normal(size=(5, 3)).astype(np.float32)), dim=-1).to(device)
+    with torch.no_grad():
+        first = qf(pts, vd, m).clone()
+    flat = m._flat()
+    off = 0
+    for (name, p), (name0, v0) in zip(m.named_parameters(), sd.items()):
+        assert name == name0 and tuple(p.shape) == tuple(v0.shape)
+        assert p.data_ptr() == flat.data_ptr() + 4 * off, name
+        exact(p.detach().cpu(), v0, name)
+        off += p.numel()
+    assert off == flat.numel()
+    # an optimiser step moves the flat vector, and the next query sees it without any copy
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=True)
+    out = qf(pts, vd, m)
+    out.square().mean().backward()
+    opt.step()
+    assert m._flat() is flat
+    exact(flat[:16], m.pts_linears[0].weight.detach().reshape(-1)[:16], "views follow the step")
+    with torch.no_grad():
+        stepped = qf(pts, vd, m).clone()
+    assert float((stepped - first).abs().max()) > 0
+    # load_state_dict copies in place; replacing a parameter's storage is noticed
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        close(qf(pts, vd, m), first, 0, 1e-6, "after load_state_dict")
+        m.rgb_linear.weight.data = (2.0 * m.rgb_linear.weight.data).clone()
+        doubled = qf(pts, vd, m).clone()
+    assert m._flat() is not flat and m.rgb_linear.weight.data_ptr() != 0
+    m2 = _model(dict(sd, **{"rgb_linear.weight": 2.0 * sd["rgb_linear.weight"]}), device)
+    with torch.no_grad():
+        close(doubled, qf(pts, vd, m2), 0, 1e-6, "re-adopted after a storage swap")
+    # the checkpoint round trip keeps names and values
+    sd2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    assert list(sd2) == list(sd)

@@ -63,6 +63,48 @@ def test_view_sampler_crop_window_and_distinct_pixels(device):
     assert torch.equal(rays[1], rd[rows, cols]) and torch.equal(rays[0], ro[rows, cols])
 
 
+def test_rays_random_draws_distinct_pixels_and_equals_rays_at(device):
+    """nerf_rays_random: n distinct pixels of the window from a keyed permutation, rays and colours equal to
+    nerf_rays_at on the pixels it reports; whole windows are permutations; seeds give different, reproducible draws."""
+    from nerf_amd import ops
+    from nerf_amd.datasets import pose_spherical
+    rng = np.random.default_rng(4)
+    for (H, W, win, n) in [(40, 60, (10, 15, 20, 30), 150), (400, 400, (0, 0, 400, 400), 1024), (7, 5, (0, 0, 7, 5), 35),
+                           (3, 3, (1, 1, 1, 1), 1), (64, 64, (0, 0, 64, 64), 4096), (33, 17, (2, 3, 30, 11), 330)]:
+        K = _camera(H, W, 50.0)
+        intr = (float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
+        c2w = pose_spherical(33.0, -30.0, 4.0)[:3, :4].to(device)
+        image = torch.from_numpy(rng.uniform(0, 1, (H * W, 3)).astype(np.float32)).to(device)
+        rays, target, pick = ops.rays_random(n, 12345, H, W, win, *intr, c2w, image, want_pick=True)
+        q = pick.cpu().numpy()
+        n_pix = win[2] * win[3]
+        assert q.min() >= 0 and q.max() < n_pix and len(set(q.tolist())) == n, (H, W, win, n)
+        if n == n_pix:
+            assert sorted(q.tolist()) == list(range(n_pix))
+        o, d, t = ops.rays_at(pick, H, W, win, *intr, c2w, image)
+        assert torch.equal(rays[0], o) and torch.equal(rays[1], d) and torch.equal(target, t)
+        again = ops.rays_random(n, 12345, H, W, win, *intr, c2w, image, want_pick=True)[2]
+        other = ops.rays_random(n, 12346, H, W, win, *intr, c2w, image, want_pick=True)[2]
+        assert torch.equal(again, pick)
+        if n_pix > 8:
+            assert not torch.equal(other, pick)
+    # no visible structure: over many seeds every pixel of a small window is drawn about equally often
+    H, W, win, n = 16, 16, (0, 0, 16, 16), 64
+    K = _camera(H, W, 20.0)
+    intr = (float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
+    c2w = pose_spherical(0.0, -30.0, 4.0)[:3, :4].to(device)
+    hits = np.zeros(256)
+    first = np.zeros(256)
+    for seed in range(400):
+        q = ops.rays_random(n, seed * 7919 + 1, H, W, win, *intr, c2w, None, want_pick=True)[2].cpu().numpy()
+        hits[q] += 1
+        first[q[0]] += 1
+    assert abs(hits.mean() - 100.0) < 1e-9 and hits.min() > 60 and hits.max() < 145, (hits.min(), hits.max())
+    assert first.max() <= 9     # 400 first draws over 256 pixels
+    with pytest.raises(RuntimeError):
+        ops.rays_random(17, 1, 4, 4, (0, 0, 4, 4), *intr, c2w, None)
+
+
 def test_ray_shuffler_epoch_and_rank_slices(device):
     from nerf_amd.datasets import pose_spherical
     from nerf_amd.raybatch import RayShuffler
