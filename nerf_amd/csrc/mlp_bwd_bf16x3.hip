@@ -82,7 +82,13 @@ __device__ __forceinline__ void layer_x3b(Stream3& st, int lane, int g, const ch
     load_start.template operator()<0>();
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
-            if constexpr (I % SLABT == 0) cur = st.advance(lane);
+            if constexpr (I % SLABT == 0) {
+#ifdef X3_STORE_BLIND   // (ablation build: the wait as it was before the stores were counted)
+                cur = st.advance(lane);
+#else
+                cur = st.template advance<(I > 0) ? x3_stores_since_open(I, NKS) : 0>(lane);
+#endif
+            }
 #ifdef X3_SPREAD   // one request of the slab after next behind each of the first six triples of a slab
             if constexpr (I % SLABT >= 1 && I % SLABT <= WAVE_BLOCKS3) {
                 if (st.next + 1 < st.nslabs) st.template fetch_block<I % SLABT - 1>(st.next + 1);

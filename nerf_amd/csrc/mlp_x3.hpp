@@ -65,10 +65,16 @@ struct Stream3 {
     // Opens slab `next`: its loads (issued two slabs ago) have landed -- those of slab next+1 may still be in flight,
     // loads return in order -- and every wave is done with slab next-1, whose buffer the request for slab next+2 reuses.
     // (One request per triple among the MFMAs, instead of six here, measured 3.6 % slower.)
-    __device__ __forceinline__ const char* advance(int lane) {
+    // STORES: vector-memory stores this wave has issued since the previous opening (the training kernels write a tile's
+    // values behind the next tile's MFMAs).  They sit in the same in-order counter behind the next slab's six loads, so
+    // the wait must allow for them: with vmcnt(6) alone every opening would also wait for that many of the NEXT slab's
+    // loads, issued one slab ago instead of two.  A smaller STORES than the truth only waits longer; a larger one would
+    // open a slab before its loads have landed.
+    template <int STORES = 0> __device__ __forceinline__ const char* advance(int lane) {
         static_assert(WAVE_BLOCKS3 == 6, "the wait below leaves one slab's loads of this wave in flight");
+        static_assert(STORES >= 0 && 6 + STORES <= 63, "vmcnt is a six-bit field");
 #ifndef X3_NO_WAIT       // (ablation builds)
-        if (next + 1 < nslabs) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (next + 1 < nslabs) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + STORES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         // a bare barrier: __syncthreads() would first wait for ALL of this wave's loads, the next slab's included.  The
@@ -85,6 +91,27 @@ struct Stream3 {
         return cur;
     }
 };
+
+// Stores of finished tiles that a layer loop of NKS k-steps per tile (layer_x3 / layer_x3b: the epilogue of tile t - 1 runs
+// piece by piece behind the k-steps of tile t, three triples behind the fragment reads, and writes 16 bytes per column
+// tile when a tile's fourth value is done) issues during the SLABT triples before triple I, i.e. since the slab opening
+// before the one at I.  For Stream3::advance<STORES>.
+constexpr int x3_stores_since_open(int I, int NKS) {
+    constexpr int DEPTH = 3, NPIECE = 4 * NCT;
+    const int div = NKS < 8 ? NKS : 8;
+    const int pps = (NPIECE + div - 1) / div;
+    int n = 0;
+    for (int J = I - SLABT; J < I; ++J) {
+        if (J < DEPTH) continue;
+        const int b = J - DEPTH, to = b / NKS, ks = b % NKS;
+        if (to == 0) continue;
+        for (int q = 0; q < pps; ++q) {
+            const int k = ks * pps + q;
+            if (k < NPIECE && (k & 3) == 3) ++n;
+        }
+    }
+    return n;
+}
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
