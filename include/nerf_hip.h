@@ -87,6 +87,14 @@ int nerf_sample_coarse(int64_t n, int S, const float* rays, int ray_stride, cons
 /* Embedder.embed (run_nerf_helpers.py:13-66): x [n,3] -> out [n, 3+6L], per frequency sin then cos. */
 int nerf_encode(int64_t n, int L, const float* x, float* out, void* stream);
 
+/* Embedder.embed for any keyword setting of the reference's Embedder whose periodic_fns are torch.sin / torch.cos in any
+ * order and number (run_nerf_helpers.py:13-47: include_input, input_dims = d, num_freqs, log or linear band spacing):
+ * out [n, (include_input ? d : 0) + n_freq * n_fn * d] = [x] ++ [fn_j(x * freqs[b])] band-major, function-minor.
+ * freqs: DEVICE, the fp32 band values as the reference computes them; bit j of cos_mask set = function j is the cosine.
+ * (nerf_encode above is the default setting, the one fused into the MLP kernels.) */
+int nerf_encode_general(int64_t n, int d, int include_input, int n_freq, const float* freqs, int n_fn, unsigned cos_mask,
+                        const float* x, float* out, void* stream);
+
 /* ---- hierarchical sampling ---------------------------------------------------------------- */
 /* sample_pdf (run_nerf_helpers.py:260-303) + the merge/sort and z_std of render_rays
  * (run_nerf.py:465-470,485) in one kernel.  z: [n,Sc] coarse depths (ascending);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "nerf_pack_rays": (_i, [_l, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _p]),
     "nerf_sample_coarse": (_i, [_l, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "nerf_encode": (_i, [_l, _i, _p, _p, _p]),
+    "nerf_encode_general": (_i, [_l, _i, _i, _i, _p, _i, ctypes.c_uint, _p, _p, _p]),
     "nerf_sample_fine": (_i, [_l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "nerf_sample_pdf": (_i, [_l, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     "nerf_composite_fwd": (_i, [_l, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),

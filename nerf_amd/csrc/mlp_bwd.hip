@@ -310,6 +310,19 @@ __global__ void __launch_bounds__(256) k_reduce_slabs(const float* __restrict__ 
     }
 }
 
+__global__ void __launch_bounds__(256) k_reduce_regions(nerfdw::SlabRegions regions, const float* __restrict__ slabs,
+                                                        int64_t slab_stride, float* __restrict__ d_params) {
+    const nerfdw::SlabRegion& R = regions.r[blockIdx.y];
+    const int64_t total = (int64_t)R.rows * R.cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / R.cols;
+        const int64_t i = R.out + row * R.ld + (e - row * R.cols);
+        float s = 0.0f;
+        for (int k = 0; k < R.nsplit; ++k) s += slabs[k * slab_stride + i];
+        d_params[i] = s;
+    }
+}
+
 // Slices per task: repeatedly give one more slice to the task whose slices are longest, until the launch
 // has one workgroup per compute unit.  cost = time of one chunk of the task relative to the others
 // (MFMA issue per SIMD, or the operand copy where that is longer).
@@ -405,6 +418,11 @@ static int run_dw(int64_t ldp, int use_viewdirs, int output_ch, const ParamOffse
 }
 
 namespace nerfdw {
+int reduce_regions(const SlabRegions& regions, const float* slabs, int64_t slab_stride, float* d_params, hipStream_t stream) {
+    if (regions.n == 0) return 0;
+    hipLaunchKernelGGL(k_reduce_regions, dim3(64, regions.n), dim3(256), 0, stream, regions, slabs, slab_stride, d_params);
+    return launched("nerf_mlp_bwd (reduce)");
+}
 int reduce_slabs(const float* slabs, int64_t slab_stride, int64_t n, int nslabs, float* d_params, hipStream_t stream) {
     hipLaunchKernelGGL(k_reduce_slabs, dim3(1024), dim3(256), 0, stream, slabs, slab_stride, n, nslabs, d_params);
     return launched("nerf_mlp_bwd (reduce)");

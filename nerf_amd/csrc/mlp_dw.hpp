@@ -17,6 +17,19 @@ inline int max_slabs(int64_t ldp) {
 // d_params[i] = sum over the first nslabs slabs, in slab order (mlp_bwd.hip)
 int reduce_slabs(const float* slabs, int64_t slab_stride, int64_t n, int nslabs, float* d_params, hipStream_t stream);
 
+// The same sum restricted to what the tasks wrote: region r is a rows x cols block (row stride ld) of the parameter
+// vector at `out`, present in the first nsplit slabs only.  Slab entries outside every region are never read, so the
+// slabs need no clearing; d_params entries outside every region are the caller's to zero.
+struct SlabRegion {
+    int64_t out;
+    int rows, cols, ld, nsplit;
+};
+struct SlabRegions {
+    SlabRegion r[44];
+    int n;
+};
+int reduce_regions(const SlabRegions& regions, const float* slabs, int64_t slab_stride, float* d_params, hipStream_t stream);
+
 // all weight and bias gradients from the saved activations `act` and the dY rows in `scratch` (mlp_dw_x3.hip)
 int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
               float* d_params, hipStream_t stream);

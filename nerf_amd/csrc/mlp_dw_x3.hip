@@ -366,15 +366,29 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
         ++tk.t[best].nsplit;
         ++used;
     }
-    int n_wg = 0, nslabs = 0;
+    int n_wg = 0;
     for (int i = 0; i < nt; ++i) {
         tk.t[i].first = n_wg;
         n_wg += tk.t[i].nsplit;
-        if (tk.t[i].nsplit > nslabs) nslabs = tk.t[i].nsplit;
     }
-    // slab entries no task covers (parameters that receive no gradient) must read as zero in the reduction
-    hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslabs * slab * sizeof(float), stream);
-    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
+    // what the reduction reads: per task its product block(s) and bias run, in the slabs of its own slices only
+    SlabRegions regions{};
+    int64_t covered = 0;
+    auto region = [&](int64_t out, int rows, int cols, int ld, int nsplit) {
+        regions.r[regions.n++] = SlabRegion{out, rows, cols, ld, nsplit};
+        covered += (int64_t)rows * cols;
+    };
+    for (int i = 0; i < nt; ++i) {
+        const DwxTask& t = tk.t[i];
+        region(t.out, t.M, t.N, t.ldc, t.nsplit);
+        if (t.kind == 1) region(t.out2, t.M, t.N, t.ldc2, t.nsplit);
+        if (t.bias >= 0) region(t.bias, 1, t.M, t.M, t.nsplit);
+    }
+    hipError_t e = hipSuccess;
+    if (covered != po.total) {   // parameters no task covers (a module's unused layers) receive a zero gradient
+        e = hipMemsetAsync(d_params, 0, (size_t)po.total * sizeof(float), stream);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
+    }
     const size_t lds = DWX_LDS_BYTES;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
@@ -382,7 +396,7 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
                        (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab);
     int rc = launched("nerf_mlp_bwd (dW, split operands)");
     if (rc) return rc;
-    return reduce_slabs(slabs, slab, po.total, nslabs, d_params, stream);
+    return reduce_regions(regions, slabs, slab, d_params, stream);
 }
 
 }  // namespace nerfdw

@@ -180,6 +180,31 @@ __global__ void __launch_bounds__(256) k_encode(int64_t n, int L, const float* _
     }
 }
 
+// run_nerf_helpers.py:13-47 with any of its keyword settings whose periodic functions are sines and cosines:
+// out = [x (include_input)] ++ [fn_j(x * freq_b) for b < n_freq for j < n_fn], each block d wide.  freqs holds the
+// reference's own fp32 band values (it evaluates 2 ** linspace or linspace on the CPU); bit j of cos_mask says that
+// function j is the cosine.
+__global__ void __launch_bounds__(256) k_encode_general(int64_t n, int d, int include_input, int n_freq,
+                                                        const float* __restrict__ freqs, int n_fn, unsigned cos_mask,
+                                                        const float* __restrict__ x, float* __restrict__ out) {
+    const int lead = include_input ? d : 0;
+    const int width = lead + n_freq * n_fn * d;
+    const int64_t total = n * width;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / width;
+        const int c = (int)(e - p * width);
+        float v;
+        if (c < lead) {
+            v = x[p * d + c];
+        } else {
+            const int q = c - lead, band = q / (n_fn * d), w = q - band * (n_fn * d), fn = w / d, dim = w - fn * d;
+            const float arg = x[p * d + dim] * freqs[band];
+            v = ((cos_mask >> fn) & 1u) ? cosf(arg) : sinf(arg);
+        }
+        out[e] = v;
+    }
+}
+
 // run_nerf.py:120-149: unit view directions (from the un-warped directions), optional NDC warp, and
 // the packed record [o d near far (viewdir)].  One thread per ray.
 __global__ void __launch_bounds__(256) k_pack_rays(int64_t n, const float* __restrict__ o_in, const float* __restrict__ d_in,
@@ -323,6 +348,19 @@ int nerf_encode(int64_t n, int L, const float* x, float* out, void* stream) {
     NERF_REQUIRE(x && out, "nerf_encode: null pointer");
     hipLaunchKernelGGL(k_encode, dim3(grid_for(n * (3 + 6 * L))), dim3(256), 0, as_stream(stream), n, L, x, out);
     return launched("nerf_encode");
+}
+
+int nerf_encode_general(int64_t n, int d, int include_input, int n_freq, const float* freqs, int n_fn, unsigned cos_mask,
+                        const float* x, float* out, void* stream) {
+    NERF_REQUIRE(n >= 0 && d >= 1 && n_freq >= 0 && n_fn >= 0 && n_fn <= 32, "nerf_encode_general: n=%lld d=%d n_freq=%d n_fn=%d",
+                 (long long)n, d, n_freq, n_fn);
+    const int64_t width = (include_input ? d : 0) + (int64_t)n_freq * n_fn * d;
+    NERF_REQUIRE(width <= 0x7fffffff, "nerf_encode_general: encoding too wide");
+    if (n == 0 || width == 0) return 0;
+    NERF_REQUIRE(x && out && (freqs || n_freq * n_fn == 0), "nerf_encode_general: null pointer");
+    hipLaunchKernelGGL(k_encode_general, dim3(grid_for(n * width)), dim3(256), 0, as_stream(stream), n, d, include_input, n_freq,
+                       freqs, n_fn, cos_mask, x, out);
+    return launched("nerf_encode_general");
 }
 
 }  // extern "C"

@@ -220,6 +220,23 @@ def encode(x: torch.Tensor, n_freq: int) -> torch.Tensor:
     return out
 
 
+def encode_general(x: torch.Tensor, include_input: bool, freqs: torch.Tensor, cos_flags: Sequence[bool]) -> torch.Tensor:
+    """[x (include_input)] ++ [fn_j(x * freqs[b])]: the reference's Embedder for any band table and any sequence of
+    sines / cosines (cos_flags[j] True = cosine); x: [..., d]."""
+    _no_input_grad(x, "encode: x")
+    x = _f32c(x, "x")
+    d = x.shape[-1]
+    freqs = _f32c(to_dev(freqs).reshape(-1), "freqs")
+    n_fn = len(cos_flags)
+    mask = sum(1 << j for j, c in enumerate(cos_flags) if c)
+    width = (d if include_input else 0) + freqs.numel() * n_fn * d
+    out = torch.empty(x.shape[:-1] + (width,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.nerf_encode_general(x.numel() // d, d, int(bool(include_input)), freqs.numel(), freqs.data_ptr(), n_fn, mask,
+                                      x.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
 def sample_fine(z: torch.Tensor, weights: torch.Tensor, u: torch.Tensor, rays: Optional[torch.Tensor],
                 want_pts: bool = True, want_samples: bool = False, want_inds: bool = False):
     """-> dict(z, pts, z_std, samples, inds).  u is [n, Si], or [Si] shared by all rays."""

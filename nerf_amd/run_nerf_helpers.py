@@ -19,8 +19,10 @@ to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
 # Positional encoding (run_nerf_helpers.py:13-66)
 # ------------------------------------------------------------------------------------------------
 class Embedder:
-    """[x, sin(2^k x), cos(2^k x)]_{k<L}.  Only the upstream default configuration exists in kernel
-    form (include_input, log-spaced powers of two, sin then cos, 3 input dims)."""
+    """[x, fn(freq x) ...] with the upstream keyword arguments (run_nerf_helpers.py:13-47).  The default setting
+    (include_input, 3 dims, log-spaced powers of two, sin then cos) is the one fused into the MLP kernels; any other
+    setting whose periodic_fns are torch.sin / torch.cos runs the general encoding kernel; other callables cannot
+    run inside a kernel and raise."""
 
     def __init__(self, **kwargs):
         self.kwargs = kwargs
@@ -29,16 +31,34 @@ class Embedder:
     def create_embedding_fn(self):
         kw = self.kwargs
         fns = list(kw.get('periodic_fns', [torch.sin, torch.cos]))
-        standard = (kw.get('include_input', True) and kw.get('input_dims', 3) == 3 and kw.get('log_sampling', True)
-                    and fns == [torch.sin, torch.cos] and kw['max_freq_log2'] == kw['num_freqs'] - 1)
-        if not standard:
-            raise NotImplementedError("Embedder: only include_input / 3 dims / log_sampling / [sin, cos] / "
-                                      "max_freq_log2 == num_freqs-1 is implemented in the HIP kernels")
-        self.n_freq = int(kw['num_freqs'])
-        self.out_dim = 3 + 6 * self.n_freq
+        d = int(kw.get('input_dims', 3))
+        n_freq = int(kw['num_freqs'])
+        self.standard = bool(kw.get('include_input', True) and d == 3 and kw.get('log_sampling', True)
+                             and fns == [torch.sin, torch.cos] and n_freq >= 1 and kw['max_freq_log2'] == n_freq - 1)
+        self.n_freq = n_freq if self.standard else None     # run_network fuses the encoding only when this is set
+        self.include_input = bool(kw.get('include_input', True))
+        self.out_dim = (d if self.include_input else 0) + d * n_freq * len(fns)
+        if self.standard:
+            return
+        bad = [f for f in fns if f not in (torch.sin, torch.cos)]
+        if bad:
+            raise NotImplementedError(f"Embedder: periodic_fns must be torch.sin / torch.cos for the HIP kernels, got {bad}")
+        self.cos_flags = [f is torch.cos for f in fns]
+        # the band values exactly as upstream evaluates them (fp32, on the CPU)
+        max_freq = kw['max_freq_log2']
+        if kw.get('log_sampling', True):
+            self.freq_bands = 2. ** torch.linspace(0., max_freq, steps=n_freq)
+        else:
+            self.freq_bands = torch.linspace(2. ** 0., 2. ** max_freq, steps=n_freq)
+        self._bands_dev = None
 
     def embed(self, inputs):
-        return ops.encode(ops.to_dev(inputs), self.n_freq)
+        x = ops.to_dev(inputs)
+        if self.standard:
+            return ops.encode(x, self.n_freq)
+        if self._bands_dev is None or self._bands_dev.device != x.device:
+            self._bands_dev = self.freq_bands.to(x.device)
+        return ops.encode_general(x, self.include_input, self._bands_dev, self.cos_flags)
 
 
 class _EmbedFn:

@@ -207,3 +207,22 @@ def test_parameters_live_in_one_flat_buffer(device):
     # the checkpoint round trip keeps names and values
     sd2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     assert list(sd2) == list(sd)
+
+
+def test_embedder_keyword_settings_against_the_reference(device):
+    """Embedder under non-default keyword settings (no identity block, linear bands, cos before sin, one or three
+    functions, 2 and 5 input dims, no bands at all): the general encoding kernel against outputs of the reference's own
+    class; the default setting keeps the kernel that is fused into the MLP; other callables are refused."""
+    from test_oracle_golden import embedder_cases
+    from nerf_amd.run_nerf_helpers import Embedder, get_embedder
+    for name, kw, x, want in embedder_cases():
+        e = Embedder(**kw)
+        assert e.out_dim == want.shape[-1] and e.n_freq is None, name
+        got = e.embed(x.to(device))
+        # arguments reach 3 * 32; sinf / cosf of the device library against the CPU's: a few ulp of a value below 1
+        close(got, want, 0, 4e-7, name)
+        close(e.embed(x.reshape(1, -1, x.shape[-1]).to(device)), want.reshape(1, -1, want.shape[-1]), 0, 4e-7, name + " 3-d input")
+    fn, width = get_embedder(10, 0)
+    assert width == 63 and fn.n_freq == 10
+    with pytest.raises(NotImplementedError):
+        Embedder(include_input=True, input_dims=3, max_freq_log2=3, num_freqs=4, log_sampling=True, periodic_fns=[torch.tanh])

@@ -97,9 +97,17 @@ def test_fused_kernels_refuse_shapes_they_do_not_cover():
     assert not m.fused_arch()          # such a module runs layer by layer through the GPU BLAS instead
     with pytest.raises(NotImplementedError):
         m._check_arch()
-    with pytest.raises(NotImplementedError):
-        Embedder(include_input=False, input_dims=3, max_freq_log2=9, num_freqs=10, log_sampling=True,
+    # a non-default Embedder setting is served by the general encoding kernel, never fused (n_freq stays unset) ...
+    e = Embedder(include_input=False, input_dims=3, max_freq_log2=9, num_freqs=10, log_sampling=True,
                  periodic_fns=[torch.sin, torch.cos])
+    assert e.n_freq is None and e.out_dim == 60 and not e.standard
+    d = Embedder(include_input=True, input_dims=3, max_freq_log2=9, num_freqs=10, log_sampling=True,
+                 periodic_fns=[torch.sin, torch.cos])
+    assert d.n_freq == 10 and d.out_dim == 63 and d.standard
+    # ... and a periodic function that is not a sine or cosine cannot run inside a kernel
+    with pytest.raises(NotImplementedError):
+        Embedder(include_input=True, input_dims=3, max_freq_log2=9, num_freqs=10, log_sampling=True,
+                 periodic_fns=[torch.sin, torch.tanh])
 
 
 def test_config_parser_reads_upstream_style_config(tmp_path):

@@ -39,6 +39,29 @@ def test_encode():
     assert O.encoded_width(10) == 63 and O.encoded_width(4) == 27 and O.encoded_width(-1) == 3
 
 
+EMBED_FNS = {ord("s"): torch.sin, ord("c"): torch.cos}
+
+
+def embedder_cases():
+    """The keyword settings of tests/golden/embedder_general.npz -> (name, kwargs, x, reference output)."""
+    g = golden("embedder_general")
+    for name in sorted(k[:-3] for k in g if k.endswith("_kw")):
+        inc, d, mf, nf, log = g[name + "_kw"]
+        kw = dict(include_input=bool(inc), input_dims=int(d), max_freq_log2=float(mf), num_freqs=int(nf),
+                  log_sampling=bool(log), periodic_fns=[EMBED_FNS[int(c)] for c in g[name + "_fns"]])
+        yield name, kw, T(g[name + "_x"]), g[name + "_out"]
+
+
+def test_embedder_keyword_settings():
+    """Embedder with include_input off, linear bands, other function orders / counts, other input widths
+    (run_nerf_helpers.py:13-47): the oracle against outputs of the reference's own class."""
+    n = 0
+    for name, kw, x, want in embedder_cases():
+        assert_pinned(O.embed_general(x, **kw), want, name)
+        n += 1
+    assert n == 7
+
+
 def test_mlp_forward_and_grads():
     g = golden("mlp")
     sd = O.random_state_dict(21)
