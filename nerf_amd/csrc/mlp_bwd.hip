@@ -317,8 +317,18 @@ __global__ void __launch_bounds__(256) k_reduce_regions(nerfdw::SlabRegions regi
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = e / R.cols;
         const int64_t i = R.out + row * R.ld + (e - row * R.cols);
+        // eight loads in flight, added in slab order (the order is what makes the gradients reproducible)
+        const float* src = slabs + i;
         float s = 0.0f;
-        for (int k = 0; k < R.nsplit; ++k) s += slabs[k * slab_stride + i];
+        int k = 0;
+        for (; k + 8 <= R.nsplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(k + j) * slab_stride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < R.nsplit; ++k) s += src[(int64_t)k * slab_stride];
         d_params[i] = s;
     }
 }
@@ -420,7 +430,16 @@ static int run_dw(int64_t ldp, int use_viewdirs, int output_ch, const ParamOffse
 namespace nerfdw {
 int reduce_regions(const SlabRegions& regions, const float* slabs, int64_t slab_stride, float* d_params, hipStream_t stream) {
     if (regions.n == 0) return 0;
-    hipLaunchKernelGGL(k_reduce_regions, dim3(64, regions.n), dim3(256), 0, stream, regions, slabs, slab_stride, d_params);
+    // one thread per element of the largest region (256 x 256 weights); the blocks of a smaller region that find nothing
+    // to do leave at once
+    int64_t most = 1;
+    for (int r = 0; r < regions.n; ++r) {
+        const int64_t elems = (int64_t)regions.r[r].rows * regions.r[r].cols;
+        if (elems > most) most = elems;
+    }
+    const int64_t bx = (most + 255) / 256;
+    hipLaunchKernelGGL(k_reduce_regions, dim3((unsigned)(bx > 512 ? 512 : bx), regions.n), dim3(256), 0, stream, regions, slabs,
+                       slab_stride, d_params);
     return launched("nerf_mlp_bwd (reduce)");
 }
 int reduce_slabs(const float* slabs, int64_t slab_stride, int64_t n, int nslabs, float* d_params, hipStream_t stream) {
