@@ -113,6 +113,12 @@ constexpr int x3_stores_since_open(int I, int NKS) {
     return n;
 }
 
+// 256-input layers (one tile per slab): nothing before the first tile is done, then two stores per slab; the 63-input
+// layer (four tiles per slab): one store per triple
+static_assert(x3_stores_since_open(8, 8) == 0 && x3_stores_since_open(16, 8) == 1 && x3_stores_since_open(24, 8) == 2 &&
+              x3_stores_since_open(120, 8) == 2 && x3_stores_since_open(8, 2) == 3 && x3_stores_since_open(16, 2) == 8,
+              "store bookkeeping of the slab ring");
+
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

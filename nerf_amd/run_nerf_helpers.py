@@ -11,7 +11,19 @@ from . import ops
 # Misc (run_nerf_helpers.py:8-10) -- the train-step tail stays in PyTorch.
 # (img2mse: mean((x - y) ** 2) as the library's fused mse_loss -- two launches forward and backward instead of eight)
 img2mse = lambda x, y: torch.nn.functional.mse_loss(x, y)
-mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))
+_LOG10 = {}
+
+
+def _log10(dev):
+    """log(10) as upstream forms it, a one-element fp32 tensor, kept per device: building it inside every call is a
+    blocking host-to-device copy per optimisation step."""
+    t = _LOG10.get(dev)
+    if t is None:
+        t = _LOG10[dev] = torch.log(torch.tensor([10.])).to(dev)
+    return t
+
+
+mse2psnr = lambda x: -10. * torch.log(x) / _log10(x.device)
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
 
 
