@@ -243,6 +243,25 @@ int nerf_mlp_bwd_data_bf16x3(int64_t n_pts, const float* d_out, const float* act
 int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdirs, int output_ch, float* scratch,
                                 float* d_params, void* stream);
 
+/* ---- nn.Linear for network shapes the fused kernels do not cover --------------------------------------------------
+ * (other --netdepth / --netwidth / --multires, --i_embed -1: NeRF.forward layer by layer, run_nerf_helpers.py:109-133,
+ * and autograd of it), fp32 on the fp32 matrix instruction; all pointers DEVICE, row-major, ld* = row strides in floats.
+ * nerf_linear_fwd:         y [n, n_out] = act(x [n, n_in] w^T + b), w [n_out, n_in] as nn.Linear stores it; b may be
+ *                          NULL; relu != 0 applies max(., 0) (a NaN stays a NaN).
+ * nerf_relu_grad:          out[i] = y[i] > 0 ? dy[i] : 0 over n values (the gradient entering a ReLU layer's products).
+ * nerf_linear_bwd_data:    dx [n, n_in] = dy [n, n_out] w.
+ * nerf_linear_bwd_weights: dw [n_out, n_in] = dy^T x and db [n_out] = column sums of dy (db may be NULL), summed over
+ *                          slices of the points in fixed order (bitwise reproducible); workspace:
+ *                          nerf_linear_workspace_floats(n_in, n_out) floats, contents irrelevant. */
+int nerf_linear_fwd(int64_t n, int n_in, int n_out, const float* x, int64_t ldx, const float* w, const float* b, int relu,
+                    float* y, int64_t ldy, void* stream);
+int nerf_relu_grad(int64_t n, const float* dy, const float* y, float* out, void* stream);
+int nerf_linear_bwd_data(int64_t n, int n_in, int n_out, const float* dy, int64_t ldy, const float* w, float* dx, int64_t ldx,
+                         void* stream);
+int64_t nerf_linear_workspace_floats(int n_in, int n_out);
+int nerf_linear_bwd_weights(int64_t n, int n_in, int n_out, const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw,
+                            float* db, float* workspace, void* stream);
+
 /* nerf_mlp_bwd_bf16x3 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): no counterpart upstream.  Same arguments and results, bit for bit, minus
  * the workspace: the dY rows and partial-gradient slabs live in an array the library's code object holds on every

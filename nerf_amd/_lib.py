@@ -69,6 +69,11 @@ SIGNATURES = {
     "nerf_gather_split3": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "nerf_mlp_bwd_data_bf16x3": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_mlp_bwd_weights_bf16x3": (_i, [_l, _p, _i, _i, _p, _p, _p]),
+    "nerf_linear_fwd": (_i, [_l, _i, _i, _p, _l, _p, _p, _i, _p, _l, _p]),
+    "nerf_relu_grad": (_i, [_l, _p, _p, _p, _p]),
+    "nerf_linear_bwd_data": (_i, [_l, _i, _i, _p, _l, _p, _p, _l, _p]),
+    "nerf_linear_workspace_floats": (_l, [_i, _i]),
+    "nerf_linear_bwd_weights": (_i, [_l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p]),
     "nerf_mlp_bwd_static_max_points": (_l, []),
     "nerf_mlp_bwd_bf16x3_static": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p]),
     "nerf_mlp_packed_bf16_bytes": (_l, [_i]),

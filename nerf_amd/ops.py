@@ -597,3 +597,71 @@ def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_pe
             return mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray)
         return mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray)
     return _FusedMLP.apply(pts, viewdirs, model, pts_per_ray, need_grad, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# nn.Linear for shapes the fused kernels do not cover
+# ------------------------------------------------------------------------------------------------
+def _rows(t: torch.Tensor, what: str) -> torch.Tensor:
+    """[..., c] -> a 2-d fp32 view whose rows are contiguous (row stride >= c): column slices of a wider buffer pass as they are."""
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"{what}: expected an fp32 tensor on a HIP device, got {t.dtype} on {t.device}")
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1 or (t2.shape[0] > 1 and t2.stride(0) < t2.shape[1]):
+        t2 = t2.contiguous()
+    return t2
+
+
+def _ld(t2: torch.Tensor) -> int:
+    return t2.stride(0) if t2.shape[0] > 1 else t2.shape[1]
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x w^T + b) with act = ReLU or identity, every product in libnerf_hip.so (linear.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x2, w2 = _rows(x, "x"), _f32c(w, "weight")
+        n, n_in = x2.shape
+        n_out = w2.shape[0]
+        assert w2.shape[1] == n_in, (x.shape, w.shape)
+        bias = None if b is None else _f32c(b, "bias")
+        y = torch.empty((n, n_out), dtype=torch.float32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            check(lib.nerf_linear_fwd(n, n_in, n_out, x2.data_ptr(), _ld(x2), w2.data_ptr(), _ptr(bias), int(bool(relu)),
+                                      y.data_ptr(), n_out, _stream()))
+        ctx.save_for_backward(x2, w2, y if relu else None)
+        ctx.has_bias = b is not None
+        ctx.lead = tuple(x.shape[:-1])
+        return y.reshape(ctx.lead + (n_out,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2, y = ctx.saved_tensors
+        n, n_in = x2.shape
+        n_out = w2.shape[0]
+        dy2 = _rows(dy, "grad")
+        dev = x2.device
+        with torch.cuda.device(dev):
+            if y is not None:
+                masked = torch.empty((n, n_out), dtype=torch.float32, device=dev)
+                dyc = dy2.contiguous()
+                check(lib.nerf_relu_grad(n * n_out, dyc.data_ptr(), y.data_ptr(), masked.data_ptr(), _stream()))
+                dy2 = masked
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((n, n_in), dtype=torch.float32, device=dev)
+                check(lib.nerf_linear_bwd_data(n, n_in, n_out, dy2.data_ptr(), _ld(dy2), w2.data_ptr(), dx.data_ptr(), n_in, _stream()))
+                dx = dx.reshape(ctx.lead + (n_in,))
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(w2)
+                db = torch.empty((n_out,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+                ws = torch.empty(lib.nerf_linear_workspace_floats(n_in, n_out), dtype=torch.float32, device=dev)
+                check(lib.nerf_linear_bwd_weights(n, n_in, n_out, dy2.data_ptr(), _ld(dy2), x2.data_ptr(), _ld(x2), dw.data_ptr(),
+                                                  _ptr(db), ws.data_ptr(), _stream()))
+        return dx, dw, db, None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False) -> torch.Tensor:
+    """torch.nn.functional.linear (+ optional ReLU) on the library's own matrix kernel, differentiable in x, weight, bias."""
+    return _Linear.apply(x, weight, bias, relu)

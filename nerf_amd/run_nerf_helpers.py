@@ -115,8 +115,8 @@ class NeRF(nn.Module):
 
     The kernel exists for the architecture every upstream config uses: D=8, W=256, skips=[4],
     input_ch=63 (L=10), input_ch_views=27 (L=4) or no view branch.  Any other shape (other --netdepth /
-    --netwidth / --multires) runs layer by layer through the GPU BLAS via torch.nn.functional -- same
-    results, autograd included, none of the fusion."""
+    --netwidth / --multires, --i_embed -1) runs layer by layer through the library's generic matrix kernel
+    (ops.linear) -- same results, autograd included (inputs too), none of the fusion."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super(NeRF, self).__init__()
@@ -281,22 +281,24 @@ class NeRF(nn.Module):
         return out.reshape(list(x.shape[:-1]) + [out.shape[-1]])
 
     def _forward_layers(self, x):
-        """The module's definition, one library GEMM per layer (run_nerf_helpers.py:109-133), for shapes the fused
-        kernels do not cover."""
-        F = torch.nn.functional
+        """The module's definition layer by layer (run_nerf_helpers.py:109-133) for shapes the fused kernels do not
+        cover: every nn.Linear (+ ReLU) is ops.linear, the library's own fp32 matrix kernel with its own backward;
+        concatenations and splits are PyTorch views and copies."""
+        def lin(layer, h, relu):
+            return ops.linear(h, layer.weight, layer.bias, relu)
         pts, views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
         h = pts
         for i, layer in enumerate(self.pts_linears):
-            h = F.relu(layer(h))
+            h = lin(layer, h, True)
             if i in self.skips:
                 h = torch.cat([pts, h], -1)
         if not self.use_viewdirs:
-            return self.output_linear(h)
-        alpha = self.alpha_linear(h)
-        h = torch.cat([self.feature_linear(h), views], -1)
+            return lin(self.output_linear, h, False)
+        alpha = lin(self.alpha_linear, h, False)
+        h = torch.cat([lin(self.feature_linear, h, False), views], -1)
         for layer in self.views_linears:
-            h = F.relu(layer(h))
-        return torch.cat([self.rgb_linear(h), alpha], -1)
+            h = lin(layer, h, True)
+        return torch.cat([lin(self.rgb_linear, h, False), alpha], -1)
 
     def load_weights_from_keras(self, weights):
         """run_nerf_helpers.py:136-163."""

@@ -226,3 +226,50 @@ def test_embedder_keyword_settings_against_the_reference(device):
     assert width == 63 and fn.n_freq == 10
     with pytest.raises(NotImplementedError):
         Embedder(include_input=True, input_dims=3, max_freq_log2=3, num_freqs=4, log_sampling=True, periodic_fns=[torch.tanh])
+
+
+@pytest.mark.parametrize("n,n_in,n_out,relu,bias", [(1, 3, 1, False, True), (70, 63, 128, True, True), (1000, 90, 64, True, False),
+                                                    (4097, 319, 256, True, True), (33, 5, 200, False, True), (2500, 130, 3, False, True)])
+def test_linear_layer_kernel_against_fp64(device, n, n_in, n_out, relu, bias):
+    """ops.linear (forward, gradient w.r.t. input, weight and bias) against an fp64 evaluation of torch.nn.functional.linear:
+    ragged sizes around the 64 x 64 tiles and the 16-value k-steps, inputs that are column slices of a wider buffer, points
+    beyond one slice of the weight-gradient product; errors at the level of the CPU's own fp32 evaluation."""
+    from nerf_amd import ops
+    rng = np.random.Generator(np.random.PCG64(n + n_in))
+    wide = T(rng.normal(size=(n, n_in + 7)).astype(np.float32))
+    w = T((rng.normal(size=(n_out, n_in)) / np.sqrt(n_in)).astype(np.float32))
+    b = T(rng.normal(size=(n_out,)).astype(np.float32)) if bias else None
+    g = T(rng.normal(size=(n, n_out)).astype(np.float32))
+
+    def run(x, w, b, dtype, fn):
+        x, w = x.clone().to(dtype).requires_grad_(True), w.clone().to(dtype).requires_grad_(True)
+        b = None if b is None else b.clone().to(dtype).requires_grad_(True)
+        y = fn(x, w, b)
+        (y * g.to(y.device, dtype)).sum().backward()
+        return [t.detach().double().cpu() for t in (y, x.grad, w.grad)] + ([b.grad.double().cpu()] if b is not None else [])
+
+    def ref(x, w, b):
+        y = torch.nn.functional.linear(x, w, b)
+        return torch.relu(y) if relu else y
+    x_cpu = wide[:, 3:3 + n_in]
+    truth = run(x_cpu, w, b, torch.float64, ref)
+    cpu32 = run(x_cpu, w, b, torch.float32, ref)
+    xd = wide.to(device)[:, 3:3 + n_in]                      # a column slice: row stride n_in + 7
+    got = run(xd, w.to(device), None if b is None else b.to(device), torch.float32, lambda x, w, b: ops.linear(x, w, b, relu))
+    # units of the ReLU that sit within rounding of zero may fall on either side in any fp32 evaluation
+    y64 = torch.nn.functional.linear(x_cpu.double(), w.double(), None if b is None else b.double())
+    safe = bool(((y64.abs() > 1e-4).all())) or not relu
+    for name, t, c, h in zip(("y", "dx", "dw", "db"), truth, cpu32, got):
+        scale = float(t.abs().max()) + 1e-30
+        err_cpu, err_gpu = float((c - t).abs().max()) / scale, float((h - t).abs().max()) / scale
+        assert h.shape == t.shape, name
+        # a wave adds its k-values one after the other in fp32: the error of such a sum grows like eps * sqrt(terms),
+        # where the CPU's blocked sums stay flatter
+        terms = {"y": n_in, "dx": n_out, "dw": n, "db": n}[name]
+        if safe or name == "y":
+            assert err_gpu <= max(2e-6, 3 * err_cpu, 1.2e-7 * np.sqrt(terms)), (name, n, n_in, n_out, err_gpu, err_cpu)
+        else:
+            assert err_gpu <= 1e-3, (name, err_gpu)
+    again = run(xd, w.to(device), None if b is None else b.to(device), torch.float32, lambda x, w, b: ops.linear(x, w, b, relu))
+    for a, c in zip(got, again):
+        exact(a, c, "bitwise reproducible")

@@ -832,8 +832,8 @@ def test_gradient_with_respect_to_inputs_is_never_silently_dropped(device):
 
 
 def test_other_network_shapes_run_layer_by_layer(device):
-    """--netdepth / --netwidth / --multires other than the shipped configs: encoding kernel + library GEMMs, same
-    numbers as the oracle, gradients included, through the same public entry points."""
+    """--netdepth / --netwidth / --multires other than the shipped configs: encoding kernel + the library's generic
+    linear-layer kernel (ops.linear), same numbers as the oracle, gradients included, through the same public entry points."""
     from nerf_amd.run_nerf import render, run_network
     from nerf_amd.run_nerf_helpers import NeRF, get_embedder
     rng = np.random.Generator(np.random.PCG64(14))

@@ -94,7 +94,7 @@ def test_state_dict_layout_matches_upstream_checkpoint_contract():
 def test_fused_kernels_refuse_shapes_they_do_not_cover():
     from nerf_amd.run_nerf_helpers import NeRF, Embedder
     m = NeRF(D=4, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True)
-    assert not m.fused_arch()          # such a module runs layer by layer through the GPU BLAS instead
+    assert not m.fused_arch()          # such a module runs layer by layer through ops.linear instead
     with pytest.raises(NotImplementedError):
         m._check_arch()
     # a non-default Embedder setting is served by the general encoding kernel, never fused (n_freq stays unset) ...
