@@ -194,7 +194,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     K = lego_camera(H, W)
     kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
     if scene == "fern":
-        # configs/fern.txt on the survey's LLFF intrinsics: 378 x 504, focal 407.57, forward-facing poses, NDC rays
+        # configs/fern.txt on the usual LLFF intrinsics at factor 8: 378 x 504, focal 407.57, forward-facing poses, NDC rays
         # (near 0, far 1), density noise 1.0, 64 + 64 samples, black background
         H, W = 378, 504
         K = np.array([[407.5658, 0, 0.5 * W], [0, 407.5658, 0.5 * H], [0, 0, 1]])
