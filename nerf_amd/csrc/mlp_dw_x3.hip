@@ -21,7 +21,9 @@
 // the board's power limit, not latency or issue slots, bounds the kernel -- the two parts add up instead of overlapping,
 // whatever the prefetch depth (one or two stages in registers, or a seven-deep LDS-DMA ring: 12.3-13.5 ms).
 // Switches for such ablation builds (tools/ab_dw.sh; the product defines none): DWX_NO_LOAD (stages re-use their first
-// loads), DWX_NO_MFMA, DWX_STREAM_ONLY (no LDS image: loads, split and bias sums only).
+// loads), DWX_NO_MFMA, DWX_STREAM_ONLY (no LDS image: loads, split and bias sums only), DWX_MAP16 (a wave's load covers
+// 4 row groups x 16 points = 256-byte runs instead of 8 x 8 = 128-byte ones: the stream-only build reads 3.42 TB/s
+// either way, so the run length is not what holds the loads back).
 // Bias gradients are fp32 row sums of dY taken in the staging path.  Partial results go to per-slice slabs that a last
 // kernel sums in fixed order (bitwise reproducible, no float atomics).
 #include "common.hpp"
@@ -116,7 +118,11 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     }
 
     // ---- staging map: thread -> (row group 32 k + rgi, point pt) of every load k
+#ifdef DWX_MAP16     // (ablation build: 256-byte runs per row group and instruction instead of 128-byte ones)
+    const int pt = lane & 15, rgi = 4 * wave + (lane >> 4);
+#else
     const int pt = 8 * (wave & 1) + (lane & 7), rgi = 8 * (wave >> 1) + (lane >> 3);
+#endif
     const float* gsrc[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
