@@ -23,7 +23,10 @@
 // Switches for such ablation builds (tools/ab_dw.sh; the product defines none): DWX_NO_LOAD (stages re-use their first
 // loads), DWX_NO_MFMA, DWX_STREAM_ONLY (no LDS image: loads, split and bias sums only), DWX_MAP16 (a wave's load covers
 // 4 row groups x 16 points = 256-byte runs instead of 8 x 8 = 128-byte ones: the stream-only build reads 3.42 TB/s
-// either way, so the run length is not what holds the loads back).
+// either way, so the run length is not what holds the loads back), DWX_SETS=3 (three register sets = three stages in
+// flight: loads and split alone go from 3.9 to 4.4 TB/s, but the 256 x 256 task already holds 248 of its 256 registers
+// and spills 50-88 of them with a third set, 18.3 ms), DWX_A_SINGLE (row-tile fragments not read ahead: 12 registers),
+// DWX_ONLY_K0 (register-pressure probe), DWX_PLAIN_LOADS (temporal loads).
 // Bias gradients are fp32 row sums of dY taken in the staging path.  Partial results go to per-slice slabs that a last
 // kernel sums in fixed order (bitwise reproducible, no float atomics).
 #include "common.hpp"
@@ -43,6 +46,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int DWX_THREADS = 512;
 constexpr int SP = 16;                 // points per stage
 constexpr int MAX_LOADS = 5;
+#ifdef DWX_SETS          // (ablation builds: three register sets of loads = three stages in flight)
+constexpr int NSETS = DWX_SETS;
+#else
+constexpr int NSETS = 2;
+#endif
+static_assert(NSETS == 2 || NSETS == 3, "the stage loop is written for two or three sets");
 
 // What a kind of task looks like to a workgroup.  The LDS image holds 128 * NL operand rows per point: the dY rows
 // first (A_TILES tiles of 32), then the input rows; a wave multiplies TM row tiles by TN column tiles (32 x 32 each).
@@ -146,11 +155,15 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
 #endif
 
     // ---- loads: two register sets, the stages after next; set (s - c0) & 1 holds stage s
-    f32x4 stage[2][NL];
+    f32x4 stage[NSETS][NL];
     auto request = [&]<int SET, int k>(int64_t chunk) {
         const int64_t ch = chunk < c1 ? chunk : c1 - 1;          // past the slice: a repeat that nothing uses
         const int64_t off = (ch >> 3) * tile_floats + (ch & 7) * (SP * 4);
+#ifdef DWX_PLAIN_LOADS   // (ablation build)
         stage[SET][k] = *reinterpret_cast<const f32x4*>(gsrc[k] + off);
+#else                    // every operand byte is read once: non-temporal loads (+1.2 % on the kernel, same-box A/B)
+        stage[SET][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gsrc[k] + off));
+#endif
     };
     float bsum[NBIAS][4];
 #pragma unroll
@@ -191,17 +204,19 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if (c0 < c1) {
-        static_for<NL>([&]<int k>() { request.template operator()<0, k>(c0); });
-        static_for<NL>([&]<int k>() { request.template operator()<1, k>(c0 + 1); });
+        static_for<NSETS>([&]<int s_>() {
+            static_for<NL>([&]<int k>() { request.template operator()<s_, k>(c0 + s_); });
+        });
         static_for<NL>([&]<int k>() {
             commit.template operator()<0, k>(smem, c0);
-            request.template operator()<0, k>(c0 + 2);
+            request.template operator()<0, k>(c0 + NSETS);
         });
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    // one stage; P = (c - c0) & 1 = the image it multiplies from = the register set that holds stage c + 2
-    auto run_stage = [&]<int P>(int64_t c) {
+    // one stage; P = (c - c0) & 1 = the image it multiplies from; S = (c - c0 + 1) % NSETS = the register set that holds
+    // stage c + 1, which is split into the other image here and re-requested for stage c + 1 + NSETS
+    auto run_stage = [&]<int P, int S>(int64_t c) {
         const char* cur = smem + P * Im::STAGE;
         char* nxt = smem + (P ^ 1) * Im::STAGE;
         bf16x8 B[TN][3];                                 // the column fragments of this stage, pieces hi, mid, lo
@@ -209,14 +224,20 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int s = 0; s < 3; ++s) B[j][s] = frag(cur + s * Im::PL, off_b + 64 * j);
-        bf16x8 A[2][3];                                  // a row tile's fragments, read one tile ahead
+#ifdef DWX_A_SINGLE   // (ablation / three-set builds: one set of row-tile fragments, read right before their products)
+        constexpr int ABUF = 1;
+#else
+        constexpr int ABUF = 2;                          // a row tile's fragments, read one tile ahead
+#endif
+        bf16x8 A[ABUF][3];
         auto read_a = [&]<int i>() {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) A[i & 1][s] = frag(cur + s * Im::PL, off_a + 64 * i);
+            for (int s = 0; s < 3; ++s) A[i % ABUF][s] = frag(cur + s * Im::PL, off_a + 64 * i);
         };
-        read_a.template operator()<0>();
+        if constexpr (ABUF == 2) read_a.template operator()<0>();
         static_for<TM>([&]<int i>() {
-            if constexpr (i + 1 < TM) read_a.template operator()<i + 1>();
+            if constexpr (ABUF == 1) read_a.template operator()<i>();
+            else if constexpr (i + 1 < TM) read_a.template operator()<i + 1>();
             __builtin_amdgcn_sched_barrier(0);
 #ifndef DWX_NO_MFMA
             // (idle waves of a head task multiply too: what they read is finite, and they store nothing)
@@ -224,15 +245,15 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 6; ++q)              // (dY piece, input piece), smallest products first
-                    acc[i][j] = mfma32(A[i & 1][PROD_W[q]], B[j][PROD_X[q]], acc[i][j]);
+                    acc[i][j] = mfma32(A[i % ABUF][PROD_W[q]], B[j][PROD_X[q]], acc[i][j]);
 #endif
             // staging of stage c + 1 behind the matrix work: load k is split when row tile group(k) multiplies, and
             // its registers are re-requested for stage c + 3
             static_for<NL>([&]<int k>() {
                 if constexpr (((k + 1) * TM - 1) / NL == i) {
-                    commit.template operator()<P ^ 1, k>(nxt, c + 1);
+                    commit.template operator()<S, k>(nxt, c + 1);
 #ifndef DWX_NO_LOAD
-                    request.template operator()<P ^ 1, k>(c + 3);
+                    request.template operator()<S, k>(c + 1 + NSETS);
 #endif
                 }
             });
@@ -240,9 +261,29 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         });
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
-    for (int64_t c = c0; c < c1; c += 2) {
-        run_stage.template operator()<0>(c);
-        run_stage.template operator()<1>(c + 1);
+    if constexpr (NSETS == 2) {
+        for (int64_t c = c0; c < c1; c += 2) {
+            run_stage.template operator()<0, 1>(c);
+            run_stage.template operator()<1, 0>(c + 1);
+        }
+    } else {
+        int64_t c = c0;
+        for (; c + 6 <= c1; c += 6) {
+            run_stage.template operator()<0, 1>(c);
+            run_stage.template operator()<1, 2>(c + 1);
+            run_stage.template operator()<0, 0>(c + 2);
+            run_stage.template operator()<1, 1>(c + 3);
+            run_stage.template operator()<0, 2>(c + 4);
+            run_stage.template operator()<1, 0>(c + 5);
+        }
+        if (c + 2 <= c1) {
+            run_stage.template operator()<0, 1>(c);
+            run_stage.template operator()<1, 2>(c + 1);
+        }
+        if (c + 4 <= c1) {
+            run_stage.template operator()<0, 0>(c + 2);
+            run_stage.template operator()<1, 1>(c + 3);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -290,9 +331,11 @@ k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __res
     float* slab = slabs + (int64_t)split * slab_stride;
     switch (task.kind) {
         case 0: dwx_loop<0>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
+#ifndef DWX_ONLY_K0   // (register-pressure probe: only the 256 x 256 task compiled)
         case 1: dwx_loop<1>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
         case 2: dwx_loop<2>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
         default: dwx_loop<3>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
+#endif
     }
 }
 
