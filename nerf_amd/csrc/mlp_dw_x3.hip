@@ -25,8 +25,10 @@
 // 4 row groups x 16 points = 256-byte runs instead of 8 x 8 = 128-byte ones: the stream-only build reads 3.42 TB/s
 // either way, so the run length is not what holds the loads back), DWX_SETS=3 (three register sets = three stages in
 // flight: loads and split alone go from 3.9 to 4.4 TB/s, but the 256 x 256 task already holds 248 of its 256 registers
-// and spills 50-88 of them with a third set, 18.3 ms), DWX_A_SINGLE (row-tile fragments not read ahead: 12 registers),
-// DWX_ONLY_K0 (register-pressure probe), DWX_PLAIN_LOADS (temporal loads).
+// and spills 50-88 of them with a third set, 18.3 ms), DWX_RAW (the third stage in flight through an LDS slot filled by
+// LDS-DMA instead of registers: 12.7 ms against 12.3, so a deeper queue of loads is not what the full kernel lacks
+// either), DWX_A_SINGLE (row-tile fragments not read ahead, 12 registers fewer: 12.4 ms), DWX_ONLY_K0 (register-pressure
+// probe), DWX_PLAIN_LOADS (temporal loads: 12.5 ms).
 // Bias gradients are fp32 row sums of dY taken in the staging path.  Partial results go to per-slice slabs that a last
 // kernel sums in fixed order (bitwise reproducible, no float atomics).
 #include "common.hpp"
@@ -46,10 +48,15 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int DWX_THREADS = 512;
 constexpr int SP = 16;                 // points per stage
 constexpr int MAX_LOADS = 5;
-#ifdef DWX_SETS          // (ablation builds: three register sets of loads = three stages in flight)
+#if defined(DWX_RAW)     // (ablation build: a third stage in flight through an LDS slot filled by LDS-DMA, tasks of <= 4 loads)
+constexpr int NSETS = 3;
+constexpr bool RAW_SLOT = true;
+#elif defined(DWX_SETS)  // (ablation builds: three register sets of loads = three stages in flight)
 constexpr int NSETS = DWX_SETS;
+constexpr bool RAW_SLOT = false;
 #else
 constexpr int NSETS = 2;
+constexpr bool RAW_SLOT = false;
 #endif
 static_assert(NSETS == 2 || NSETS == 3, "the stage loop is written for two or three sets");
 
@@ -67,7 +74,9 @@ template <int NL> struct Image {
     static constexpr int PL = SP * PS;            // bytes per piece
     static constexpr int STAGE = 3 * PL;
 };
-constexpr size_t DWX_LDS_BYTES = 2 * (size_t)Image<MAX_LOADS>::STAGE;
+constexpr size_t DWX_RAW_BYTES = 4 * 8 * 1024;        // the LDS-DMA slot: one KiB per load and wave
+constexpr size_t DWX_LDS_BYTES = !RAW_SLOT || 2 * (size_t)Image<MAX_LOADS>::STAGE > 2 * (size_t)Image<4>::STAGE + DWX_RAW_BYTES
+                                     ? 2 * (size_t)Image<MAX_LOADS>::STAGE : 2 * (size_t)Image<4>::STAGE + DWX_RAW_BYTES;
 static_assert(DWX_LDS_BYTES <= 160 * 1024, "LDS of one compute unit");
 
 struct DwxTask {
@@ -155,10 +164,18 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
 #endif
 
     // ---- loads: two register sets, the stages after next; set (s - c0) & 1 holds stage s
-    f32x4 stage[NSETS][NL];
+    constexpr bool RAW = RAW_SLOT && NL <= 4;             // set 2 = the LDS slot behind the two images
+    f32x4 stage[RAW ? 2 : NSETS][NL];
+    char* const raw_mine = smem + 2 * Im::STAGE + wave * 1024;   // + 8 KiB per load; the lane's 16 bytes follow by themselves
     auto request = [&]<int SET, int k>(int64_t chunk) {
         const int64_t ch = chunk < c1 ? chunk : c1 - 1;          // past the slice: a repeat that nothing uses
         const int64_t off = (ch >> 3) * tile_floats + (ch & 7) * (SP * 4);
+        if constexpr (RAW && SET == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this lane's read of the slot (commit) has returned
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[k] + off),
+                                             (__attribute__((address_space(3))) void*)(raw_mine + k * 8192), 16, 0, 0);
+            return;
+        }
 #ifdef DWX_PLAIN_LOADS   // (ablation build)
         stage[SET][k] = *reinterpret_cast<const f32x4*>(gsrc[k] + off);
 #else                    // every operand byte is read once: non-temporal loads (+1.2 % on the kernel, same-box A/B)
@@ -172,7 +189,14 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     // split the four rows of load k of stage `chunk` into image `img`; count them for the bias if the stage is inside
     // the slice
     auto commit = [&]<int SET, int k>(char* img, int64_t chunk) {
-        const f32x4 v = stage[SET][k];
+        f32x4 v;
+        if constexpr (RAW && SET == 2) {
+            // issued after this load: the rest of its stage, two stages of register loads, this stage's first k requests
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL - 1) : "memory");
+            v = *reinterpret_cast<const f32x4*>(raw_mine + k * 8192 + lane * 16);
+        } else {
+            v = stage[SET][k];
+        }
         bf16x4 h, m, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
