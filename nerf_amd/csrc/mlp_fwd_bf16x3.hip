@@ -197,6 +197,7 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
         park(2 * ct + 0, e);
         park(2 * ct + 1, e + 8);
         const int pw = wave * WAVE_PTS + ct * 16 + (lane & 15);   // point inside the tile
+#ifndef X3_NO_ENC_SAVE   // (ablation build: what the 4-byte stores of the encodings cost)
         if constexpr (SAVE) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -204,6 +205,7 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
                 tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid[ct] && f >= 0) ? e[q] : 0.0f;
             }
         }
+#endif
         if (VIEWDIRS) {
             const int64_t ray = pl / pts_per_ray;
             const float v0 = viewdirs[ray * 3 + 0], v1 = viewdirs[ray * 3 + 1], v2 = viewdirs[ray * 3 + 2];
@@ -217,6 +219,7 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
             dd[6] = g == 0 ? v0 : (g == 1 ? v2 : 0.0f);
             dd[7] = g == 0 ? v1 : 0.0f;
             park(2 * NCT + ct, dd);
+#ifndef X3_NO_ENC_SAVE
             if constexpr (SAVE) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -226,6 +229,7 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
                     tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid[ct] && f >= 0) ? dd[q] : 0.0f;
                 }
             }
+#endif
         }
     }
 
