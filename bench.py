@@ -158,8 +158,15 @@ def hbm_kernels(prof):
         a[0] += units
         a[1] += s.elapsed_time(e) * 1e-3
         a[2] += 1
-    return {k: {"launches": c, "mean_us": round(1e6 * t / c, 1), "GBps_algorithmic": round(b / t / 1e9, 1),
-                "frac_of_hbm_peak": round(b / t / 1e9 / HBM_PEAK_GBS, 4)} for k, (b, t, c) in agg.items() if t > 0}
+    out = {}
+    for k, (b, t, c) in agg.items():
+        if t <= 0:
+            continue
+        out[k] = {"launches": c, "mean_us": round(1e6 * t / c, 1), "GBps_algorithmic": round(b / t / 1e9, 1),
+                  "frac_of_hbm_peak": round(b / t / 1e9 / HBM_PEAK_GBS, 4), "kib_per_launch": round(b / c / 1024, 1)}
+        if b / c < 16e6:   # under 2 us of traffic at the HBM peak: the launch itself (4-8 us between two events) is what is timed
+            out[k]["note"] = "launch-bound at this size: the bytes of one launch are under 2 us of HBM traffic"
+    return out
 
 
 # algorithmic FLOP per sample point of the three MLP kernels of a train step, and the matrix instruction each runs on
