@@ -63,10 +63,11 @@ def _host_staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """Concatenate per-rank row blocks cut by shard_bounds (blocks differ by at most one row)."""
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None, force_collective: bool = False) -> torch.Tensor:
+    """Concatenate per-rank row blocks cut by shard_bounds (blocks differ by at most one row).  force_collective: go
+    through the collective even in a group of one rank."""
     rank, world = _world(group)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         return local
     rows = (n_total + world - 1) // world
     pad = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -85,7 +86,8 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     return torch.cat(parts, 0)
 
 
-def render_sharded(H: int, W: int, K, chunk: int, rays, render_fn: Optional[Callable] = None, group=None, **render_kwargs):
+def render_sharded(H: int, W: int, K, chunk: int, rays, render_fn: Optional[Callable] = None, group=None,
+                   force_collective: bool = False, **render_kwargs):
     """Render `rays` = (rays_o [N,3], rays_d [N,3]) with the ray list split across ranks.
 
     Returns (rgb [N,3], disp [N], acc [N]) complete on every rank.  render_fn defaults to
@@ -99,12 +101,13 @@ def render_sharded(H: int, W: int, K, chunk: int, rays, render_fn: Optional[Call
     b, e = shard_bounds(n, rank, world)
     rgb, disp, acc, _ = render_fn(H, W, K, chunk=chunk, rays=(rays_o[b:e], rays_d[b:e]), **render_kwargs)
     packed = torch.cat([rgb.reshape(-1, 3), disp.reshape(-1, 1), acc.reshape(-1, 1)], -1)  # one collective, 20 B/ray
-    full = all_gather_rows(packed.contiguous(), n, group)
+    full = all_gather_rows(packed.contiguous(), n, group, force_collective)
     return full[:, 0:3], full[:, 3], full[:, 4]
 
 
 def render_path_sharded(render_poses, hwf, K, chunk: int, render_kwargs, render_factor: int = 0,
-                        render_fn: Optional[Callable] = None, group=None, savedir: Optional[str] = None):
+                        render_fn: Optional[Callable] = None, group=None, savedir: Optional[str] = None,
+                        force_collective: bool = False):
     """The pose loop of render_path (run_nerf.py:163-201) with the FRAMES dealt round-robin to the ranks: rank r
     renders poses r, r + world, ...; one all_gather of the finished frames returns the whole sequence, in pose
     order, on every rank as (rgbs [N,H,W,3], disps [N,H,W]) tensors.  With savedir every rank writes the PNGs of its
@@ -139,7 +142,7 @@ def render_path_sharded(render_poses, hwf, K, chunk: int, render_kwargs, render_
     if pending is not None:
         write(*pending)
     dev, dtype = (mine[0].device, mine[0].dtype) if mine else (None, torch.float32)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         frames = torch.stack(mine, 0)
     else:
         if dev is None:   # more ranks than frames: this rank has nothing to render but still joins the collective
@@ -179,28 +182,84 @@ def unflatten_into_gradients(bucket: torch.Tensor, params: Sequence[torch.Tensor
     torch._foreach_copy_(dst, src)
 
 
-def allreduce_gradients(params: Iterable[torch.Tensor], group=None) -> None:
-    """Average the gradients of `params` over all ranks with a single all_reduce."""
+MAX_IN_PLACE_RUNS = 8
+
+
+def gradient_runs(params: Sequence[torch.Tensor]) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """(runs, rest): the gradients of `params`, in order, grouped into maximal runs that already lie back to back in
+    one storage, each run returned as ONE flat tensor that aliases those .grad tensors; `rest` = the parameters whose
+    gradient is missing, not contiguous or not fp32.  The fused MLP backward hands autograd views of one flat
+    gradient vector per network (ops._FusedMLP.backward), which autograd keeps as the .grad tensors, so a NeRF pair
+    gives two runs and an empty rest: the exchange can then work in place, with no concatenation and no copy back."""
+    runs, rest = [], []
+    first, count, end = None, 0, None
+
+    def close():
+        if first is not None:
+            runs.append(first.as_strided((count,), (1,), first.storage_offset()))
+    for p in params:
+        g = p.grad
+        if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.numel() == 0:
+            rest.append(p)
+            continue
+        here = g.data_ptr()
+        if (first is not None and here == end and g.device == first.device
+                and g.untyped_storage().data_ptr() == first.untyped_storage().data_ptr()):
+            count += g.numel()
+        else:
+            close()
+            first, count = g, g.numel()
+        end = here + 4 * g.numel()
+    close()
+    return runs, rest
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> None:
+    if _host_staged(t, group):
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def allreduce_gradients(params: Iterable[torch.Tensor], group=None, force_collective: bool = False) -> dict:
+    """Average the gradients of `params` over all ranks.  Gradients that already lie back to back in memory (one run
+    per NeRF network, see gradient_runs) are all-reduced IN PLACE, one collective per run and one multi-tensor scale;
+    whatever is left over travels as one concatenated bucket that is copied back.  force_collective: issue the
+    collectives even in a group of one rank (a one-GPU check that the calls of the multi-GPU run execute).
+    -> {"collectives", "in_place_bytes", "bucket_bytes"} of this call."""
     params = [p for p in params if p.requires_grad]
     rank, world = _world(group)
-    if world == 1 or not params:
-        return
-    bucket = flatten_gradients(params)
-    if _host_staged(bucket, group):
-        host = bucket.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        bucket.copy_(host)
-    else:
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
-    bucket.mul_(1.0 / world)
-    unflatten_into_gradients(bucket, params)
+    info = {"collectives": 0, "in_place_bytes": 0, "bucket_bytes": 0}
+    grouped = dist.is_available() and dist.is_initialized()
+    if not params or not grouped or (world == 1 and not force_collective):
+        return info
+    runs, rest = gradient_runs(params)
+    if len(runs) > MAX_IN_PLACE_RUNS:   # separately allocated gradients (stock autograd): one bucket beats a collective each
+        runs, rest = [], params
+    for r in runs:
+        _all_reduce_sum(r, group)
+        info["collectives"] += 1
+        info["in_place_bytes"] += 4 * r.numel()
+    if runs:
+        torch._foreach_mul_(runs, 1.0 / world)
+    if rest:
+        bucket = flatten_gradients(rest)
+        _all_reduce_sum(bucket, group)
+        bucket.mul_(1.0 / world)
+        unflatten_into_gradients(bucket, rest)
+        info["collectives"] += 1
+        info["bucket_bytes"] += 4 * bucket.numel()
+    return info
 
 
-def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=None) -> None:
+def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=None, force_collective: bool = False) -> None:
     """Make every rank start from rank `src`'s weights (one flat broadcast)."""
     params = list(params)
     rank, world = _world(group)
-    if world == 1 or not params:
+    grouped = dist.is_available() and dist.is_initialized()
+    if not params or not grouped or (world == 1 and not force_collective):
         return
     with torch.no_grad():
         flat = torch.cat([p.detach().reshape(-1) for p in params])

@@ -594,6 +594,45 @@ def test_mlp_backward_sizes_and_no_view_branch(device, mlp_dtype):
             assert err_gpu <= max(3e-5, 2.0 * err_cpu), (k, n, s, err_gpu, err_cpu)
 
 
+@TRAIN_DTYPES
+def test_mlp_backward_at_the_data_parallel_batch(device, mlp_dtype):
+    """The per-GPU batch of the data-parallel lego configuration: 8192 rays x 64 coarse samples = 524,288 points through
+    one network in ONE backward pass, where every slice of the weight-gradient stage is 8 times longer than at the
+    largest size above.  Truth = oracle autograd in fp64, accumulated over chunks of 32,768 points (gradients are sums
+    over points); the fp32 CPU gradients are accumulated the same way in fp32.  Same ReLU-margin mask and the same
+    bound as at the smaller sizes (run_nerf.py:862-874, run_nerf_helpers.py:109-133)."""
+    rng = np.random.Generator(np.random.PCG64(12))
+    qf = _query_fn()
+    n, s, step = 8192, 64, 512   # 512 rays x 64 samples = 32,768 points per CPU chunk
+    sd = _peaky(O.random_state_dict(8192), 5.0)
+    m = _model(sd, device)
+    m.mlp_dtype = mlp_dtype
+    pts = T(rng.uniform(-3, 3, size=(n, s, 3)).astype(np.float32))
+    vd = T(rng.normal(size=(n, 3)).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    G = T(rng.normal(size=(n, s, 4)).astype(np.float32))
+    keep = torch.cat([_relu_margin(sd, pts[a:a + step], vd[a:a + step], True) > 1e-5 for a in range(0, n, step)], 0)
+    assert float(keep.float().mean()) > 0.75, "the mask must leave most of the batch in (about 2,300 ReLU units per point)"
+    G = G * keep[..., None].float()
+    raw = qf(pts.to(device), vd.to(device), m)
+    assert raw.shape == (n, s, 4)
+    (raw * G.to(device)).sum().backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    acc32 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    for a in range(0, n, step):
+        (O.query_field(pts[a:a + step].double(), vd[a:a + step].double(), p64) * G[a:a + step].double()).sum().backward()
+        p32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        (O.query_field(pts[a:a + step], vd[a:a + step], p32) * G[a:a + step]).sum().backward()
+        for k in acc32:
+            acc32[k] += p32[k].grad
+    for k, p in m.named_parameters():
+        truth = p64[k].grad
+        scale = float(truth.abs().max())
+        err_gpu = float((p.grad.cpu().double() - truth).abs().max()) / scale
+        err_cpu = float((acc32[k].double() - truth).abs().max()) / scale
+        assert err_gpu <= max(3e-5, 2.0 * err_cpu), (k, err_gpu, err_cpu)
+
+
 def test_mlp_backward_at_scale(device):
     """57,600 points = 1.2e8 ReLU units: a handful of them sit within fp32 rounding of zero, and which side they fall on
     differs between ANY two fp32 evaluations (this kernel, the CPU, fp64), each flip moving the gradients by ~1e-3 of

@@ -147,3 +147,63 @@ def test_single_process_is_a_no_op():
     assert torch.equal(p.grad, torch.full((3,), 2.0))
     t = torch.arange(6.).reshape(3, 2)
     assert all_gather_rows(t, 3) is t
+
+
+def _dp_flat(rank, world):
+    """Gradients that are views of one flat vector per network (what the fused MLP backward hands autograd) plus one
+    separately allocated gradient and one parameter without a gradient."""
+    from nerf_amd.parallel import allreduce_gradients, gradient_runs
+    shapes = [(4, 3), (4,), (2, 4), (2,)]
+    nets = []
+    for n in range(2):
+        ps = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        flat = torch.arange(sum(p.numel() for p in ps), dtype=torch.float32) * (rank + 1) + 100.0 * n
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        nets.append((ps, flat))
+    lone = torch.nn.Parameter(torch.zeros(5))
+    lone.grad = torch.full((5,), float(rank + 1))
+    empty = torch.nn.Parameter(torch.zeros(3))          # never touched by the loss: no gradient
+    params = nets[0][0] + [lone] + nets[1][0] + [empty]
+    runs, rest = gradient_runs(params)
+    shape_ok = [r.numel() for r in runs] == [26, 5, 26] and rest == [empty]
+    before = [p.grad.data_ptr() for p in params if p.grad is not None]
+    info = allreduce_gradients(params)
+    same_memory = before == [p.grad.data_ptr() for p in params[:-1]]
+    mean_scale = sum(r + 1 for r in range(world)) / world
+    ok = True
+    for n, (ps, flat) in enumerate(nets):
+        want = torch.arange(flat.numel(), dtype=torch.float32) * mean_scale + 100.0 * n
+        ok = ok and torch.allclose(flat, want) and torch.allclose(torch.cat([p.grad.reshape(-1) for p in ps]), want)
+    ok = ok and torch.allclose(lone.grad, torch.full((5,), mean_scale)) and torch.equal(empty.grad, torch.zeros(3))
+    return bool(ok and shape_ok and same_memory), info
+
+
+def test_gradients_laid_out_back_to_back_are_reduced_in_place():
+    for world in (2, 3):
+        res = _run(_dp_flat, world=world)
+        assert all(ok for ok, _ in res), res
+        info = res[0][1]
+        assert info["collectives"] == 4 and info["in_place_bytes"] == 4 * (26 + 5 + 26) and info["bucket_bytes"] == 12
+
+
+def _forced(rank, world):
+    from nerf_amd.parallel import all_gather_rows, allreduce_gradients, broadcast_parameters, render_sharded
+    p = torch.nn.Parameter(torch.arange(6.).reshape(2, 3))
+    p.grad = torch.full((2, 3), 3.0)
+    info = allreduce_gradients([p], force_collective=True)
+    broadcast_parameters([p], force_collective=True)
+    t = torch.arange(10.).reshape(5, 2)
+    g = all_gather_rows(t, 5, force_collective=True)
+    o, d = torch.randn(9, 3), torch.randn(9, 3)
+    rgb, disp, acc = render_sharded(3, 3, None, 4, (o, d), render_fn=_fake_render, force_collective=True)
+    want = _fake_render(3, 3, None, 4, (o, d))
+    return bool(info["collectives"] == 1 and torch.equal(p.grad, torch.full((2, 3), 3.0)) and torch.equal(g, t) and g is not t
+                and torch.equal(p.detach(), torch.arange(6.).reshape(2, 3)) and torch.equal(rgb, want[0])
+                and torch.equal(disp, want[1]) and torch.equal(acc, want[2]))
+
+
+def test_a_group_of_one_rank_can_be_made_to_run_every_collective():
+    assert _run(_forced, world=1) == [True]
