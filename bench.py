@@ -22,6 +22,14 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                 the reference on the golden fixtures) timed on this host on a bounded ray sample -- the
                 only place this file touches oracle/;
   train:        (when the backward is available) one lego train step, rays/s.
+Every figure that depends on the chip's clock carries the mean shader clock and board power sampled while it was
+timed (clock_ghz_mean, power_w_mean; nerf_amd/gpustat.py).
+
+The headline is timed first and then guarded (class Guard): an extra leg that overruns its deadline, or a peer rank
+that dies, makes rank 0 print the headline with "extras_aborted" and leave with status 1 instead of hanging.  Legs
+with collectives run under LegSync: the ranks agree beforehand that each could build its inputs and meet again
+afterwards.  Rehearsal aids (never set by a normal run): BENCH_SINGLE_DEVICE=1 and BENCH_DIST_BACKEND=gloo put several
+ranks on one GPU, BENCH_FAIL_IN=<leg>:<rank> raises inside a leg, BENCH_LEG_SECONDS shortens the deadlines.
 """
 import argparse
 import json
@@ -190,47 +198,61 @@ def train_kernel_rooflines(prof):
     return out
 
 
-def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=False, scene="lego"):
+def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=False, scene="lego", ready=None, card=None,
+               hook=None):
     """The upstream optimisation step (run_nerf.py:826-883, no_batching mode) on synthetic targets: rays of one
     400x400 view, n_rand random pixels, render with jitter, two MSE terms, backward, (all-reduce,) Adam, lr decay.
-    graphed: the same step recorded into HIP graphs after three eager steps and replayed (nerf_amd.graph_step)."""
-    from nerf_amd import ops, parallel
+    graphed: the same step recorded into HIP graphs after three eager steps and replayed (nerf_amd.graph_step).
+    ready: in a multi-rank run, the agreement (one all_reduce(MIN) of a flag) that every rank could build its inputs,
+    taken before the first collective of the leg; hook: called once after the warm-up steps (failure injection)."""
+    from nerf_amd import gpustat, ops, parallel
     from nerf_amd.run_nerf import render
     from nerf_amd.run_nerf_helpers import img2mse
-    H = W = 400
-    K = lego_camera(H, W)
-    kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
-    if scene == "fern":
-        # configs/fern.txt on the usual LLFF intrinsics at factor 8: 378 x 504, focal 407.57, forward-facing poses, NDC rays
-        # (near 0, far 1), density noise 1.0, 64 + 64 samples, black background
-        H, W = 378, 504
-        K = np.array([[407.5658, 0, 0.5 * W], [0, 407.5658, 0.5 * H], [0, 0, 1]])
-        kw = dict(kwargs, perturb=1.0, raw_noise_std=1.0, N_importance=64, white_bkgd=False, near=0., far=1., lindisp=False)
-        del kw["ndc"]     # as upstream's create_nerf leaves it for LLFF: render() defaults to ndc=True
-    pts_per_ray = 2 * kw["N_samples"] + kw["N_importance"]
     params = list(models[0].parameters()) + list(models[1].parameters())
-    saved = [p.detach().clone() for p in params]
-    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=graphed, fused=True)   # as create_nerf
-    stepper = None
-    if graphed:
-        from nerf_amd.graph_step import GraphedTrainStep
-        stepper = GraphedTrainStep(H, W, K, kw, params, opt, n_rand, chunk=1024 * 32, eager_steps=3,
-                                   between=(lambda: parallel.allreduce_gradients(params)) if world > 1 else None)
-        warmup = max(warmup, 5)    # three eager steps, the recording, one replay
-    torch.cuda.empty_cache()   # the render legs leave the caching allocator full of view-sized blocks
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    thetas = np.linspace(-180, 180, 41)[:-1]
-    n_views = 8
-    poses = torch.stack([orbit_pose(thetas[(5 * i) % 40]) for i in range(n_views)], 0)
-    if scene == "fern":   # cameras at z ~ 0 looking down -z, shifted sideways along a line
-        poses = torch.tensor([[[1., 0, 0, 0.2 * np.sin(0.7 * i)], [0, 1., 0, 0.1 * np.cos(0.7 * i)], [0, 0, 1., 0.05 * i % 0.3]]
-                              for i in range(n_views)], dtype=torch.float32)
-    images = torch.rand(n_views, H, W, 3, device=dev, generator=gen)
-    # the package's own no_batching sampler (run_nerf.py:833-854): one view per step, N_rand distinct pixels of it,
-    # rays and target colours of exactly those pixels from one kernel
-    from nerf_amd.raybatch import ViewSampler
-    sampler = ViewSampler(images, poses, list(range(n_views)), H, W, K, n_rand, device=dev, seed=seed)
+    setup_error = None
+    try:
+        H = W = 400
+        K = lego_camera(H, W)
+        kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
+        if scene == "fern":
+            # configs/fern.txt on the usual LLFF intrinsics at factor 8: 378 x 504, focal 407.57, forward-facing poses, NDC
+            # rays (near 0, far 1), density noise 1.0, 64 + 64 samples, black background
+            H, W = 378, 504
+            K = np.array([[407.5658, 0, 0.5 * W], [0, 407.5658, 0.5 * H], [0, 0, 1]])
+            kw = dict(kwargs, perturb=1.0, raw_noise_std=1.0, N_importance=64, white_bkgd=False, near=0., far=1., lindisp=False)
+            del kw["ndc"]     # as upstream's create_nerf leaves it for LLFF: render() defaults to ndc=True
+        pts_per_ray = 2 * kw["N_samples"] + kw["N_importance"]
+        saved = [p.detach().clone() for p in params]
+        opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=graphed, fused=True)   # as create_nerf
+        stepper = None
+        if graphed:
+            from nerf_amd.graph_step import GraphedTrainStep
+            stepper = GraphedTrainStep(H, W, K, kw, params, opt, n_rand, chunk=1024 * 32, eager_steps=3,
+                                       between=(lambda: parallel.allreduce_gradients(params)) if world > 1 else None)
+            warmup = max(warmup, 5)    # three eager steps, the recording, one replay
+        torch.cuda.empty_cache()   # the render legs leave the caching allocator full of view-sized blocks
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        thetas = np.linspace(-180, 180, 41)[:-1]
+        n_views = 8
+        poses = torch.stack([orbit_pose(thetas[(5 * i) % 40]) for i in range(n_views)], 0)
+        if scene == "fern":   # cameras at z ~ 0 looking down -z, shifted sideways along a line
+            poses = torch.tensor([[[1., 0, 0, 0.2 * np.sin(0.7 * i)], [0, 1., 0, 0.1 * np.cos(0.7 * i)], [0, 0, 1., 0.05 * i % 0.3]]
+                                  for i in range(n_views)], dtype=torch.float32)
+        images = torch.rand(n_views, H, W, 3, device=dev, generator=gen)
+        # the package's own no_batching sampler (run_nerf.py:833-854): one view per step, N_rand distinct pixels of it,
+        # rays and target colours of exactly those pixels from one kernel
+        from nerf_amd.raybatch import ViewSampler
+        sampler = ViewSampler(images, poses, list(range(n_views)), H, W, K, n_rand, device=dev, seed=seed)
+    except Exception as exc:
+        setup_error = exc
+    if ready is not None and not ready(setup_error is None):
+        return {"skipped": "a rank could not build the inputs of this leg",
+                "error_on_this_rank": repr(setup_error) if setup_error is not None else None}
+    if setup_error is not None:
+        raise setup_error
+
+    ar_events, ar_info, timing = [], {}, [False]
 
     def one(i):
         batch_rays, target = sampler.next(i, img_i=i % n_views)
@@ -241,10 +263,10 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
         opt.zero_grad()
         loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
         loss.backward()
-        if world > 1:   # one flat bucket, one all_reduce; bracketed by events on the stream the collective is ordered on
+        if world > 1:   # the gradient exchange, bracketed by events on the stream the collectives are ordered on
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ev[0].record()
-            parallel.allreduce_gradients(params)
+            ar_info.update(parallel.allreduce_gradients(params))
             ev[1].record()
             if timing[0]:
                 ar_events.append(ev)
@@ -253,46 +275,59 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
             g['lr'] = 5e-4 * (0.1 ** (i / (500 * 1000)))
         return loss
 
-    ar_events, timing = [], [False]
-    for i in range(warmup):
-        one(i)
-    timing[0] = True
-    ops.PROFILE = None if graphed else []     # events recorded inside a graph cannot be timed
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = one(warmup + i)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    with torch.no_grad():
-        for p, s0 in zip(params, saved):
-            p.copy_(s0)
-    for m in models:
-        m.invalidate_packs()
+    try:
+        for i in range(warmup):
+            one(i)
+        if hook is not None:
+            hook()
+        timing[0] = True
+        ops.PROFILE = None if graphed else []     # events recorded inside a graph cannot be timed
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        with gpustat.Sampler(card) as stat:
+            t0 = time.perf_counter()
+            for i in range(steps):
+                loss = one(warmup + i)
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        prof = ops.PROFILE
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+    finally:     # whatever happened, the next leg starts from the benchmark's weights
+        ops.PROFILE = None
+        with torch.no_grad():
+            for p, s0 in zip(params, saved):
+                p.copy_(s0)
+        for m in models:
+            m.invalidate_packs()
+    held = {k: v for k, v in stat.summary().items() if k in ("clock_ghz_mean", "power_w_mean")}
     if graphed:
-        return {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
-                "n_rand_per_gpu": n_rand, "steps": steps, "final_loss": float(loss.detach()),
-                "note": "the same step replayed from two HIP graphs (render+loss+backward | Adam)"}
+        return dict({"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
+                     "n_rand_per_gpu": n_rand, "steps": steps, "final_loss": float(loss.detach()),
+                     "note": "the same step replayed from two HIP graphs (render+loss+backward | Adam)"}, **held)
     kern = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name in TRAIN_KERNEL_FLOP)
     flop = n_rand * pts_per_ray * FLOP_PER_POINT_TRAIN * steps
     res = {"rays_per_s": round(n_rand * steps * world / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "n_rand_per_gpu": n_rand,
            "points_per_ray": pts_per_ray, "steps": steps, "final_loss": float(loss.detach()), "mlp_kernels_share_of_step": round(kern / dt, 4),
            "mlp_tflops_algorithmic": round(flop / kern / 1e12, 2) if kern > 0 else None,
            "kernels": train_kernel_rooflines(prof), "hbm_kernels": hbm_kernels(prof)}
+    res.update(held)
+    for k in res["kernels"].values():   # the three kernels ran back to back under the same clock and power
+        k.update(held)
     if ar_events:
         ar = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+        in_place = ar_info.get("bucket_bytes", 1) == 0
         res["allreduce"] = {"ms_per_step": round(ar, 4), "share_of_step": round(ar * 1e-3 * steps / dt, 5),
                             "bytes": 4 * sum(p.numel() for p in params), "backend": torch.distributed.get_backend(),
-                            "what": "flatten + one all_reduce(SUM) of both networks' gradients + scale + copy back, HIP events"}
+                            "collectives_per_step": ar_info.get("collectives"),
+                            "what": ("in place: one all_reduce(SUM) per network on its flat gradient vector + one multi-tensor scale, "
+                                     "no concatenation, no copy back; HIP events") if in_place else
+                                    "flatten + one all_reduce(SUM) of both networks' gradients + scale + copy back, HIP events"}
     return res
 
 
@@ -338,6 +373,148 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+class Guard:
+    """Makes sure a finished headline is printed exactly once, whatever the extras after it do.
+
+    The headline (the contract's fields, timed first) is handed over with set_headline(); every extra leg then runs
+    between arm(leg, seconds) and disarm().  Two side threads watch the run: a watchdog that fires when a leg overruns
+    its deadline (a rank stuck in a collective that a failed peer never entered), and -- because the launcher answers a
+    dead rank with SIGTERM to the others -- a thread that waits for SIGTERM synchronously (the signal is blocked in
+    every other thread, so it is received even while the main thread sits inside a collective).  Either way rank 0
+    writes the headline with "extras_aborted" naming the leg and the process leaves with os._exit(1): a fresh exit, no
+    re-execution, no Python finalisers that could wait for the GPU.  Ranks other than 0 wait `rank_grace` seconds
+    longer, so that rank 0's line is out before the launcher starts to tear the job down."""
+
+    def __init__(self, rank, write=None, exit_fn=None, rank_grace=15.0, catch_sigterm=True, poll_s=0.25):
+        import threading
+        self.rank = rank
+        self._write = write or (lambda text: os.write(1, text.encode()))
+        self._exit = exit_fn or os._exit
+        self._grace = 0.0 if rank == 0 else rank_grace
+        self._lock = threading.Lock()
+        self._headline = None
+        self._printed = False
+        self._leg, self._deadline = None, None
+        self._poll = poll_s
+        self._stop = threading.Event()
+        self._threads = [threading.Thread(target=self._watch, name="bench-watchdog", daemon=True)]
+        if catch_sigterm:
+            import signal
+            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})   # inherited by every thread started from here on
+            self._threads.append(threading.Thread(target=self._wait_sigterm, name="bench-sigterm", daemon=True))
+        for t in self._threads:
+            t.start()
+
+    def set_headline(self, out):
+        with self._lock:
+            self._headline = json.loads(json.dumps(out))   # a snapshot: later legs add to the caller's dict, not to this one
+
+    def arm(self, leg, seconds):
+        with self._lock:
+            self._leg, self._deadline = leg, time.monotonic() + seconds + self._grace
+
+    def disarm(self):
+        with self._lock:
+            self._leg, self._deadline = None, None
+
+    def finish(self, out):
+        """The complete line, on rank 0, unless an abort has already printed the headline."""
+        with self._lock:
+            self._leg, self._deadline = None, None
+            if self.rank == 0 and not self._printed:
+                self._printed = True
+                self._write(json.dumps(out) + "\n")
+        self._stop.set()
+
+    def abort(self, why):
+        with self._lock:
+            if self.rank == 0 and self._headline is not None and not self._printed:
+                self._printed = True
+                line = dict(self._headline, extras_aborted=why)
+                self._write(json.dumps(line) + "\n")
+        self._exit(1)
+
+    def _watch(self):
+        while not self._stop.wait(self._poll):
+            with self._lock:
+                late = self._deadline is not None and time.monotonic() > self._deadline
+                leg = self._leg
+            if late:
+                print(f"bench.py rank {self.rank}: leg '{leg}' overran its deadline; leaving", file=sys.stderr, flush=True)
+                self.abort(f"{leg}: deadline overrun on rank {self.rank}")
+                return
+
+    def _wait_sigterm(self):
+        import signal
+        signal.sigwait({signal.SIGTERM})
+        with self._lock:
+            leg = self._leg
+        print(f"bench.py rank {self.rank}: SIGTERM during '{leg}'; leaving", file=sys.stderr, flush=True)
+        self.abort(f"{leg}: SIGTERM on rank {self.rank} (a peer rank died)")
+
+
+class LegSync:
+    """Keeps the ranks of a multi-rank run in step around extras that contain collectives.
+
+    ready(ok): one all_reduce(MIN) of a flag BEFORE a leg -- every rank says whether it could build the leg's inputs, and
+    the leg is skipped everywhere if any could not.
+    done(leg, seconds): a rendezvous AFTER a leg through the process group's key-value store (no collective): a rank
+    that raised inside the leg still reports in, so if every rank arrives, none is stuck in a collective and the
+    collectives of the leg were matched -- the run may go on; a rank that never arrives trips the deadline."""
+
+    def __init__(self, world, dev=None, store=None):
+        self.world, self.dev, self.store = world, dev, store
+        self._n = 0
+
+    def ready(self, ok):
+        if self.world == 1:
+            return bool(ok)
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    def run(self, out, guard, key, body, prepare=None, collective=False, seconds=150.0):
+        """One extra leg under the watchdog: out[key] = body(prepare()) or {"error": ...}.  collective: the leg contains
+        collectives -- all ranks first agree that each could build its inputs (prepare), and meet again afterwards; a
+        rank that cannot be accounted for ends the run with the headline."""
+        guard.arm(key, seconds)
+        state, err = None, None
+        try:
+            if prepare is not None:
+                state = prepare()
+        except Exception as exc:
+            err = repr(exc)
+        together = collective and self.world > 1
+        if together and not self.ready(err is None):
+            out[key] = {"skipped": "a rank could not build the inputs of this leg", "error_on_this_rank": err}
+            guard.disarm()
+            return
+        if err is not None:
+            out[key] = {"error": err}
+        else:
+            try:
+                out[key] = body(state) if prepare is not None else body()
+            except Exception as exc:  # the headline number must survive a failure of this extra
+                out[key] = {"error": repr(exc)}
+        if together and not self.done(key, seconds + (0.0 if guard.rank == 0 else 20.0)):
+            guard.abort(f"{key}: a rank did not come out of the leg (seen from rank {guard.rank})")
+        guard.disarm()
+
+    def done(self, leg, seconds=120.0):
+        if self.world == 1 or self.store is None:
+            return True
+        self._n += 1
+        key = f"bench/leg{self._n}/{leg}"
+        self.store.add(key, 1)
+        t_end = time.monotonic() + seconds
+        while self.store.add(key, 0) < self.world:
+            if time.monotonic() > t_end:
+                return False
+            time.sleep(0.02)
+        return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,7 +532,7 @@ def main():
 
     if os.environ.get("BENCH_VERBOSE"):   # where a hung multi-rank run is stuck: stacks of all threads after N seconds
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["BENCH_VERBOSE"]), exit=True)
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_VERBOSE"]), exit=False)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -366,14 +543,23 @@ def main():
     if os.environ.get("BENCH_SINGLE_DEVICE"):
         local = 0
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    guard = Guard(rank)      # before any other thread exists: the threads it starts own SIGTERM
+    leg_seconds = float(os.environ.get("BENCH_LEG_SECONDS", "150"))      # deadline of one extra leg, under the group's timeout
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    store = None
     if world > 1:
         import torch.distributed as dist
+        from datetime import timedelta
+        # a collective a peer never joins fails after 180 s instead of waiting for ever
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timedelta(seconds=180))
+        store = dist.distributed_c10d._get_default_store()
+    legs = LegSync(world, dev, store)
+    from nerf_amd import gpustat
+    card = gpustat.find_card(gpustat.device_pci_bus_id(local))
 
     from nerf_amd import ops
     from nerf_amd.run_nerf import render
@@ -402,16 +588,18 @@ def main():
             secs = float(t.item())
         return secs
 
+    guard.arm("headline", 600.0)
     for i in range(args.warmup):
         step(i)
     ops.PROFILE = []
     sync()
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last = step(args.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
+    with gpustat.Sampler(card) as stat:
+        t0 = time.perf_counter()
+        last = None
+        for i in range(args.steps):
+            last = step(args.warmup + i)
+        sync()
+        dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     dt = max_over_ranks(dt)
     rays_per_step = H * W
@@ -450,6 +638,7 @@ def main():
 
     default_kind = "bf16x3"    # what mlp_dtype = 'f32' (the default) runs
     roofline = mlp_roofline(prof, default_kind, dt)
+    roofline.update({k: v for k, v in stat.summary().items() if k != "samples"})   # the clock and power this run was held at
 
     out = {"metric": "rays/sec per GPU (train step + render) at 64+128 samples; 1/2/4/8 GPU scaling",
            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -468,41 +657,71 @@ def main():
                       "parallelism": f"ray/view-sharded x{world}, no collective"},
            "roofline": roofline, "hbm_kernels": hbm_kernels(prof)}
     if world > 1:
+        # one record per rank, gathered: N distinct devices prove that the N ranks ran on N GPUs
+        props = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "device_index": local, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                "pci": gpustat.device_pci_bus_id(local)}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
         out["world_seen_by_backend"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                                        "devices_visible": torch.cuda.device_count()}
+                                        "devices_visible": torch.cuda.device_count(), "ranks": seen,
+                                        "distinct_devices": len({(d["uuid"], d["pci"], d["device_index"]) for d in seen})}
+    guard.set_headline(out)    # from here on the contract's line survives whatever an extra does
+    guard.disarm()
+
+    def extra(key, body, prepare=None, collective=False, seconds=None):
+        legs.run(out, guard, key, body, prepare=prepare, collective=collective, seconds=seconds or leg_seconds)
 
     def timed_variant(dtype_name):
+        """The headline's render with another arithmetic, timed on this rank alone (no collective, no barrier)."""
         for m in models:
             m.mlp_dtype = dtype_name
-        step(0)
-        ops.PROFILE = []
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        sync()
-        secs = time.perf_counter() - t0
-        records, ops.PROFILE = ops.PROFILE, None
-        for m in models:
-            m.mlp_dtype = 'f32'
-        return secs, records
+        try:
+            step(0)
+            ops.PROFILE = []
+            torch.cuda.synchronize()
+            with gpustat.Sampler(card) as st:
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    step(args.warmup + i)
+                torch.cuda.synchronize()
+                secs = time.perf_counter() - t0
+            records, ops.PROFILE = ops.PROFILE, None
+        finally:
+            ops.PROFILE = None
+            for m in models:
+                m.mlp_dtype = 'f32'
+        return secs, records, st.summary()
 
-    if default_kind == "bf16x3":
+    def leg_f32_mfma():
         # the same render on the fp32 matrix instruction (mlp_dtype = 'f32_mfma'), with that kernel's own roofline
-        dt32, prof32 = timed_variant('f32_mfma')
-        out["render_f32_mfma"] = {"rays_per_s": round(rays_per_step * args.steps / dt32, 1), "ms_per_step": round(1e3 * dt32 / args.steps, 3),
-                                  "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "note": "per-GPU, this rank only",
-                                  "roofline": mlp_roofline(prof32, "mfma32", dt32)}
+        dt32, prof32, st32 = timed_variant('f32_mfma')
+        r32 = mlp_roofline(prof32, "mfma32", dt32)
+        r32.update({k: v for k, v in st32.items() if k in ("clock_ghz_mean", "power_w_mean")})
+        return {"rays_per_s": round(rays_per_step * args.steps / dt32, 1), "ms_per_step": round(1e3 * dt32 / args.steps, 3),
+                "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "note": "per-GPU, this rank only", "roofline": r32}
 
-    if not args.no_bf16:
+    def leg_bf16():
         # the bf16-operand / fp32-accumulate variant of the same render (reduced precision: reported, never `value`)
-        dt16, prof16 = timed_variant('bf16')
+        dt16, prof16, st16 = timed_variant('bf16')
         k16 = [(n, s.elapsed_time(e) * 1e-3) for (name, n, s, e) in prof16 if name == "mlp_fwd_bf16"]
         s16 = sum(t for _, t in k16)
-        out["render_bf16"] = {"rays_per_s": round(rays_per_step * args.steps / dt16, 1), "ms_per_step": round(1e3 * dt16 / args.steps, 3),
-                              "mlp_tflops_algorithmic": round(sum(n for n, _ in k16) * FLOP_PER_POINT_FWD / s16 / 1e12, 1) if s16 > 0 else None,
-                              "mlp_share_of_step": round(s16 / dt16, 4), "dtype": "bf16 operands, f32 accumulate",
-                              "note": "per-GPU, this rank only; tolerance vs fp32: raw within 2e-2 of scale, rgb within 1e-2"}
+        return {"rays_per_s": round(rays_per_step * args.steps / dt16, 1), "ms_per_step": round(1e3 * dt16 / args.steps, 3),
+                "mlp_tflops_algorithmic": round(sum(n for n, _ in k16) * FLOP_PER_POINT_FWD / s16 / 1e12, 1) if s16 > 0 else None,
+                "mlp_share_of_step": round(s16 / dt16, 4), "dtype": "bf16 operands, f32 accumulate",
+                "clock_ghz_mean": st16.get("clock_ghz_mean"), "power_w_mean": st16.get("power_w_mean"),
+                "note": "per-GPU, this rank only; tolerance vs fp32: raw within 2e-2 of scale, rgb within 1e-2"}
+
+    if default_kind == "bf16x3":
+        extra("render_f32_mfma", leg_f32_mfma)
+    if not args.no_bf16:
+        extra("render_bf16", leg_bf16)
+
+    fail_in = os.environ.get("BENCH_FAIL_IN", "")     # rehearsal aid "<leg>:<rank>": that rank raises inside that leg
+
+    def injected_failure(key):
+        if fail_in == f"{key}:{rank}":
+            raise RuntimeError(f"injected failure in {key} on rank {rank} (BENCH_FAIL_IN)")
 
     if world > 1 or os.environ.get("BENCH_FORCE_SHARDED"):
         # ONE view cut into world_size contiguous ray slices, reassembled with one all_gather of 20 bytes per ray (strong
@@ -510,14 +729,17 @@ def main():
         # samples, chunk 65536); reported next to `value`, never instead of it
         from nerf_amd import parallel
         from nerf_amd.run_nerf_helpers import get_rays
-        shared_poses = [orbit_pose(thetas[i % 40]).to(dev) for i in range(n_views)]   # the same view on every rank
 
-        def sharded(kw, chunk_rays, n_timed):
+        def sharded_inputs():
+            return [orbit_pose(thetas[i % 40]).to(dev) for i in range(n_views)]   # the same view on every rank
+
+        def sharded(key, kw, chunk_rays, n_timed, shared_poses):
             def frame(i):
                 with torch.no_grad():
                     o, d = get_rays(H, W, K, shared_poses[i % n_views])
                     return parallel.render_sharded(H, W, K, chunk_rays, (o, d), **kw)
             frame(0)
+            injected_failure(key)
             sync()
             t0 = time.perf_counter()
             for i in range(n_timed):
@@ -528,34 +750,27 @@ def main():
                     "views": n_timed, "ranks": world, "rays_per_rank": -(-rays_per_step // world), "chunk": chunk_rays,
                     "samples": f"{kw['N_samples']}+{kw['N_importance']}", "gathered_bytes_per_view": rays_per_step * 20,
                     "rgb_checksum": float(full[0].double().sum().item())}
-        legs = [("render_one_view_sharded", kwargs, chunk, args.steps)]
+        sharded_legs = [("render_one_view_sharded", kwargs, chunk, args.steps)]
         if not args.no_stress:
-            legs.append(("render_one_view_sharded_stress", dict(kwargs, N_samples=256, N_importance=512), 1024 * 64, 1))
-        for key, kw, chunk_rays, n_timed in legs:
-            try:
-                out[key] = sharded(kw, chunk_rays, n_timed)
-            except Exception as exc:  # the headline number must survive a failure of this extra
-                out[key] = {"error": repr(exc)}
+            sharded_legs.append(("render_one_view_sharded_stress", dict(kwargs, N_samples=256, N_importance=512), 1024 * 64, 1))
+        for key, kw, chunk_rays, n_timed in sharded_legs:
+            extra(key, lambda poses_, key=key, kw=kw, c=chunk_rays, n=n_timed: sharded(key, kw, c, n, poses_),
+                  prepare=sharded_inputs, collective=True)
 
     if not args.no_train:
+        ready = legs.ready if world > 1 else None
         # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)
         for key, n_rand, k, w, seed in (("train_8192", 8192, 10, 2, 4321), ("train", 1024, 20, 5, 1234)):
-            try:
-                out[key] = time_train(models, kwargs, dev, world, n_rand, k, w, seed=seed + rank)
-            except Exception as exc:  # the headline number must survive a failure of an extra
-                out[key] = {"error": repr(exc)}
+            extra(key, lambda key=key, n_rand=n_rand, k=k, w=w, seed=seed: time_train(
+                models, kwargs, dev, world, n_rand, k, w, seed=seed + rank, ready=ready, card=card,
+                hook=lambda key=key: injected_failure(key)), collective=True)
         if world == 1:   # configs[2]: fern-shaped step (NDC, density noise, 64 + 64 samples), single-GPU extra
-            try:
-                out["train_fern"] = time_train(models, kwargs, dev, world, 1024, 10, 3, seed=99, scene="fern")
-            except Exception as exc:
-                out["train_fern"] = {"error": repr(exc)}
+            extra("train_fern", lambda: time_train(models, kwargs, dev, world, 1024, 10, 3, seed=99, scene="fern", card=card))
         if world == 1:   # single-GPU extra; the multi-rank runs keep to the eager step
-            try:
-                out["train_graphed"] = time_train(models, kwargs, dev, world, 1024, 10, 5, seed=1234 + rank, graphed=True)
-            except Exception as exc:  # the eager numbers above stand without it
-                out["train_graphed"] = {"error": repr(exc)}
+            extra("train_graphed", lambda: time_train(models, kwargs, dev, world, 1024, 10, 5, seed=1234 + rank, graphed=True, card=card))
 
     if rank == 0:
+        guard.arm("cpu_baseline", 900.0)
         if args.cpu_rays > 0 and world == 1:   # the CPU leg is a single-GPU-run extra: ranks of a multi-GPU run do not wait for it
             cpu_rps, cpu_out, pick = cpu_baseline(sds, poses[-1].cpu(), H, W, K, args.cpu_rays)
             got = last[0].reshape(-1, 3)[pick.to(dev)].cpu()
@@ -570,9 +785,12 @@ def main():
                 out["cpu_baseline"]["train_rays_per_s"] = round(cpu_train, 1)
                 out["cpu_baseline"]["train_sample"] = "3 timed steps (after 1 warm-up) of the oracle's train step, N_rand=1024, 64+128 samples"
                 out["cpu_baseline"]["train_speedup_per_gpu"] = round(out["train"]["rays_per_s"] / world / cpu_train, 1)
-        print(json.dumps(out), flush=True)
+    guard.finish(out)      # the ONE line (rank 0), unless an abort already printed the headline
     if world > 1:
+        guard.arm("shutdown", 60.0)
+        dist.barrier()
         dist.destroy_process_group()
+        guard.disarm()
 
 
 if __name__ == "__main__":

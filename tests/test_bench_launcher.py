@@ -66,3 +66,105 @@ def test_pmc_traffic_file_is_consistent():
         per = (2 * e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024 / e["points_per_launch"]
         assert abs(per - e["hbm_bytes_per_point"]) < 0.01 * per, (name, per)
         assert os.path.exists(os.path.join(ROOT, e["source"]))
+
+
+def test_guard_prints_the_headline_once_and_only_once():
+    import time
+    import bench
+    written, exits = [], []
+    g = bench.Guard(0, write=written.append, exit_fn=exits.append, catch_sigterm=False, poll_s=0.02)
+    g.abort("too early")                       # no headline yet: nothing to print, still leaves
+    assert written == [] and exits == [1]
+    out = {"metric": "m", "value": 1.0}
+    g.set_headline(out)
+    out["late_extra"] = {"x": 1}               # added after the snapshot: must not appear in an aborted line
+    g.arm("slow_leg", 0.05)
+    time.sleep(0.5)                            # the watchdog fires
+    assert len(written) == 1 and exits == [1, 1]
+    line = json.loads(written[0])
+    assert line["value"] == 1.0 and "late_extra" not in line and line["extras_aborted"].startswith("slow_leg")
+    g.finish(out)                              # the abort already printed: no second line
+    assert len(written) == 1
+    # the ordinary course: disarmed legs never fire, finish prints the complete line
+    written2 = []
+    g2 = bench.Guard(0, write=written2.append, exit_fn=exits.append, catch_sigterm=False, poll_s=0.02)
+    g2.set_headline(out)
+    g2.arm("quick_leg", 0.05)
+    g2.disarm()
+    time.sleep(0.2)
+    g2.finish(out)
+    assert len(written2) == 1 and json.loads(written2[0])["late_extra"] == {"x": 1} and exits == [1, 1]
+    # ranks other than 0 never print
+    written3 = []
+    g3 = bench.Guard(1, write=written3.append, exit_fn=exits.append, catch_sigterm=False, rank_grace=0.0, poll_s=0.02)
+    g3.set_headline(out)
+    g3.abort("x")
+    g3.finish(out)
+    assert written3 == []
+
+
+GUARDED_RANKS = textwrap.dedent("""
+    import json, os, sys, time
+    from datetime import timedelta
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import bench
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    guard = bench.Guard(rank, rank_grace=2.0)
+    dist.init_process_group("gloo", timeout=timedelta(seconds=60))
+    legs = bench.LegSync(world, None, dist.distributed_c10d._get_default_store())
+    out = {"metric": "m", "value": 42.0}
+    guard.set_headline(out)
+    mode = sys.argv[1]
+
+    def summed():
+        t = torch.ones(1) * (rank + 1)
+        dist.all_reduce(t)
+        return {"sum": float(t)}
+
+    def cannot_prepare():
+        if rank == 1:
+            raise RuntimeError("no inputs on rank 1")
+        return None
+
+    def broken(_state=None):
+        if rank == 1:
+            if mode == "die":
+                os._exit(9)
+            raise RuntimeError("rank 1 fails inside the leg")   # and never joins the collective below
+        return summed()
+
+    legs.run(out, guard, "good", summed, collective=True, seconds=20)
+    legs.run(out, guard, "unprepared", lambda s: summed(), prepare=cannot_prepare, collective=True, seconds=20)
+    legs.run(out, guard, "good_again", summed, collective=True, seconds=20)
+    if mode in ("raise", "die"):
+        legs.run(out, guard, "stress", broken, collective=True, seconds=3)
+        legs.run(out, guard, "never_reached", summed, collective=True, seconds=20)
+    guard.finish(out)
+    dist.destroy_process_group()
+""") % ROOT
+
+
+@pytest.mark.parametrize("mode", ["clean", "raise", "die"])
+def test_a_rank_that_fails_inside_a_collective_leg_cannot_take_the_headline_with_it(tmp_path, capfd, mode):
+    """Two gloo ranks: every rank agrees to skip a leg one of them cannot prepare; when rank 1 raises inside a leg (or
+    dies) and leaves rank 0 alone in the collective, the run ends within the leg's deadline, rank 0's headline is on
+    stdout with `extras_aborted`, and the status is not 0."""
+    import time
+    import bench
+    script = tmp_path / "ranks.py"
+    script.write_text(GUARDED_RANKS)
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(2, [mode], script=str(script))
+    took = time.monotonic() - t0
+    out, err = capfd.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, (out, err[-2000:])
+    got = json.loads(lines[0])
+    assert got["value"] == 42.0
+    if mode == "clean":
+        assert rc == 0 and got["good"] == {"sum": 3.0} and got["good_again"] == {"sum": 3.0}
+        assert "skipped" in got["unprepared"] and "extras_aborted" not in got
+    else:
+        assert rc != 0 and got["extras_aborted"].startswith("stress") and "never_reached" not in got
+        assert took < 50.0, took
