@@ -499,6 +499,7 @@ class LegSync:
                 out[key] = {"error": repr(exc)}
         if together and not self.done(key, seconds + (0.0 if guard.rank == 0 else 20.0)):
             guard.abort(f"{key}: a rank did not come out of the leg (seen from rank {guard.rank})")
+        guard.set_headline(out)     # a later abort prints every leg that finished
         guard.disarm()
 
     def done(self, leg, seconds=120.0):
