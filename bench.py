@@ -47,7 +47,9 @@ FLOP_PER_POINT_FWD = 1186816          # 2 * 593,408 MAC: one NeRF.forward on one
 FLOP_PER_POINT_TRAIN = 3489024        # forward + dW + dX
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X v_mfma_f32_32x32x2_f32 peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 PEAK_BF16_MATRIX_TFLOPS = 2500.0      # MI355X dense bf16 matrix peak
-SPLIT_PRODUCTS = 6                    # bf16 matrix instructions the split-operand kernel issues per fp32-accurate product
+PEAK_F16_MATRIX_TFLOPS = 2500.0       # MI355X dense fp16 matrix peak (same rate as bf16)
+SPLIT_PRODUCTS = 6                    # bf16 matrix instructions the three-piece kernels issue per fp32-accurate product
+PAIR_PRODUCTS = 3                     # fp16 matrix instructions the two-piece kernel issues per fp32-accurate product
 
 
 def pmc_traffic():
@@ -609,13 +611,25 @@ def main():
 
     # dominant kernel: fused encode + MLP forward, timed per launch with events on the launch stream
     def mlp_roofline(records, kind, step_secs):
-        k = [(n, st.elapsed_time(en) * 1e-3) for (name, n, st, en) in records if name == ("mlp_fwd_bf16x3" if kind == "bf16x3" else "mlp_fwd")]
+        record = {"f16x2": "mlp_fwd_f16x2", "bf16x3": "mlp_fwd_bf16x3", "mfma32": "mlp_fwd"}[kind]
+        k = [(n, st.elapsed_time(en) * 1e-3) for (name, n, st, en) in records if name == record]
         n_pts = sum(n for n, _ in k)
         secs = sum(t for _, t in k)
         achieved = n_pts * FLOP_PER_POINT_FWD / secs / 1e12 if secs > 0 else 0.0
-        pmc = traffic.get("k_mlp_fwd_bf16x3" if kind == "bf16x3" else "k_mlp_fwd_x4", {})
+        pmc = traffic.get({"f16x2": "k_mlp_fwd_f16x2", "bf16x3": "k_mlp_fwd_bf16x3", "mfma32": "k_mlp_fwd_x4"}[kind], {})
         per_point = pmc.get("hbm_bytes_per_point")
-        if kind == "bf16x3":
+        if kind == "f16x2":
+            # fp32-accurate products out of three fp16 matrix instructions each: the ceiling for the ALGORITHMIC (fp32) FLOP
+            # is a third of the dense fp16 peak; `executed` is what the matrix pipe actually ran.  The timed span is the
+            # entry point's two launches: the two-piece kernel and the three-piece kernel on the tiles it marked (none here)
+            peak = PEAK_F16_MATRIX_TFLOPS / PAIR_PRODUCTS
+            r = {"bound": "mfma", "kernel": "k_mlp_fwd_f16x2<viewdirs> (v_mfma_f32_16x16x32_f16 on two fp16 pieces per operand, "
+                 "three piece products per fp32 product, fp32 accumulate) + k_mlp_fwd_bf16x3 on marked tiles", "achieved": round(achieved, 2),
+                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                 "peak_note": "dense fp16 matrix peak (2500 TFLOP/s) / 3 instructions per product; the fp32 matrix peak is 157.3",
+                 "executed_f16_tflops": round(PAIR_PRODUCTS * achieved, 1),
+                 "vs_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 3)}
+        elif kind == "bf16x3":
             # fp32-accurate products out of six bf16 matrix instructions each: the ceiling for the ALGORITHMIC (fp32) FLOP
             # is a sixth of the dense bf16 peak; `executed` is what the matrix pipe actually ran
             peak = PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS
@@ -637,7 +651,7 @@ def main():
                   "flop_per_point": FLOP_PER_POINT_FWD, "mlp_share_of_step": round(secs / step_secs, 4)})
         return r
 
-    default_kind = "bf16x3"    # what mlp_dtype = 'f32' (the default) runs
+    default_kind = "f16x2"     # what a no-grad query of mlp_dtype = 'f32' (the default) runs
     roofline = mlp_roofline(prof, default_kind, dt)
     roofline.update({k: v for k, v in stat.summary().items() if k != "samples"})   # the clock and power this run was held at
 
@@ -647,11 +661,12 @@ def main():
            "vs_baseline": None,
            "value_note": "whole-job aggregate over all ranks (the contract's `value`); value_per_gpu is the metric's per-GPU figure",
            "value_per_gpu": round(value / world, 1),
-           "dtype": "f32 via 3xbf16 splits" if default_kind == "bf16x3" else "f32",
-           "dtype_note": ("fp32 inputs, outputs and accuracy: every product is rebuilt from exact three-way bf16 splits of both "
-                          "operands (six bf16 matrix instructions, fp32 accumulate); error against fp64 equal to the fp32 matrix "
-                          "instruction's, all parity tolerances unchanged; render_f32_mfma is the same render on the fp32 "
-                          "matrix instruction") if default_kind == "bf16x3" else "fp32 matrix instruction",
+           "dtype": "f32 via 2xfp16 pieces",
+           "dtype_note": ("fp32 inputs, outputs and accuracy: every product is rebuilt from two fp16 pieces per operand (three "
+                          "fp16 matrix instructions, fp32 accumulate), tiles whose operands leave fp16's normal range are "
+                          "recomputed from exact three-way bf16 splits; error against fp64 at or below the fp32 matrix "
+                          "instruction's, all parity tolerances unchanged; render_bf16x3 is the same render on the three-piece "
+                          "kernel alone, render_f32_mfma on the fp32 matrix instruction"),
            "data": "synthetic",
            "config": {"workload": f"lego {H}x{W} render_only, N_samples=64, N_importance=128, chunk={chunk}, white_bkgd, "
                                   "use_viewdirs, one view per step per GPU", "rays_per_step_per_gpu": rays_per_step,
@@ -713,8 +728,16 @@ def main():
                 "clock_ghz_mean": st16.get("clock_ghz_mean"), "power_w_mean": st16.get("power_w_mean"),
                 "note": "per-GPU, this rank only; tolerance vs fp32: raw within 2e-2 of scale, rgb within 1e-2"}
 
-    if default_kind == "bf16x3":
-        extra("render_f32_mfma", leg_f32_mfma)
+    def leg_bf16x3():
+        # the same render on the three-piece bf16 kernel alone (mlp_dtype = 'bf16x3'): the default of the rounds before
+        dt3, prof3, st3 = timed_variant('bf16x3')
+        r3 = mlp_roofline(prof3, "bf16x3", dt3)
+        r3.update({k: v for k, v in st3.items() if k in ("clock_ghz_mean", "power_w_mean")})
+        return {"rays_per_s": round(rays_per_step * args.steps / dt3, 1), "ms_per_step": round(1e3 * dt3 / args.steps, 3),
+                "dtype": "f32 via 3xbf16 splits", "note": "per-GPU, this rank only", "roofline": r3}
+
+    extra("render_bf16x3", leg_bf16x3)
+    extra("render_f32_mfma", leg_f32_mfma)
     if not args.no_bf16:
         extra("render_bf16", leg_bf16)
 

@@ -133,7 +133,10 @@ int nerf_composite_bwd(int64_t n, int S, const float* raw, const float* z, const
 /* The network is NeRF(D=8, W=256, skips=[4]) (run_nerf_helpers.py:73-133) with L=10 / L=4
  * encodings fused in (run_nerf.py:40-66).  Weights are consumed from packed streams built from the flat concatenation
  * of the module's parameters in state_dict order.  One forward and one backward per arithmetic:
- *   split operands on the bf16 matrix instruction (fp32-accurate, the default):  nerf_mlp_fwd_bf16x3 / nerf_mlp_bwd_bf16x3
+ *   two fp16 pieces per operand on the fp16 matrix instruction (fp32-accurate, the default of the no-grad render):
+ *                                                                                nerf_mlp_fwd_f16x2
+ *   three bf16 pieces per operand on the bf16 matrix instruction (fp32-accurate, the default of training):
+ *                                                                                nerf_mlp_fwd_bf16x3 / nerf_mlp_bwd_bf16x3
  *   the fp32 matrix instruction:                                                 nerf_mlp_fwd_x4     / nerf_mlp_bwd_x4
  *   bf16 operands, fp32 sums (inference only, reduced precision):                nerf_mlp_fwd_bf16
  *   already-encoded inputs, as NeRF.forward(x) receives them upstream:           nerf_mlp_fwd_encoded */
@@ -198,6 +201,26 @@ int64_t nerf_mlp_packed_bf16x3_bytes(int use_viewdirs);
 int nerf_pack_weights_bf16x3(int use_viewdirs, int output_ch, const float* params, void* packed_bf16x3, void* stream);
 int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                         int use_viewdirs, int output_ch, const void* packed_bf16x3, float* out, float* act, void* stream);
+
+/* fp32-accurate forward on the fp16 matrix instruction, two pieces per operand (same arguments and outputs as
+ * nerf_mlp_fwd_bf16x3; NeRF.forward, run_nerf_helpers.py:109-133, behind run_nerf.py:40-66): x ~ hi + lo * 2^-11 with
+ * hi = fp16(x), lo = fp16((x - hi) * 2^11), a product = hi.hi + (hi.lo + lo.hi) * 2^-11 in two fp32 accumulators -- three
+ * matrix instructions per product where the bf16 scheme issues six.  22 of an fp32's 24 significand bits are kept, which
+ * stays below the rounding of the fp32 accumulation as long as the leading piece is a normal fp16; the kernel checks
+ * that per layer and point (largest magnitude in [2^-11, 2^15)) and, per layer, for the weights, and writes one word per
+ * tile of nerf_mlp_f16x2_tile_points() points into tile_flags (DEVICE, ceil(n_pts / tile points) words, caller-owned,
+ * need not be initialised): 0 = the tile's outputs stand, 1 = the range was left.  With packed_bf16x3 (the stream of
+ * nerf_pack_weights_bf16x3) the marked tiles are then recomputed by the three-piece kernel in a second launch on the
+ * same stream, so out (and act) hold fp32-accurate results whatever the magnitudes, non-finite classes as documented
+ * for nerf_mlp_fwd_bf16x3; with packed_bf16x3 = NULL only the first launch runs and the caller reads the flags.
+ * packed_f16x2: nerf_mlp_packed_f16x2_bytes() bytes built by nerf_pack_weights_f16x2 from the flat parameter vector
+ * (1,160 or 960 pairs of 1 KiB A-operand blocks hi | lo, the fp32 tables, 16 range words). */
+int64_t nerf_mlp_packed_f16x2_bytes(int use_viewdirs);
+int64_t nerf_mlp_f16x2_tile_points(void);
+int nerf_pack_weights_f16x2(int use_viewdirs, int output_ch, const float* params, void* packed_f16x2, void* stream);
+int nerf_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
+                       int use_viewdirs, int output_ch, const void* packed_f16x2, const void* packed_bf16x3,
+                       float* out, float* act, uint32_t* tile_flags, void* stream);
 
 /* Backward of the forward entries w.r.t. the parameters (inputs carry no gradient upstream: run_nerf.py:467 detaches
  * the samples): what autograd derives for run_nerf_helpers.py:109-133.  d_out [n_pts,out_ch]; act from any forward

@@ -150,7 +150,11 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
 template <bool VIEWDIRS, bool SAVE>
 __global__ void __launch_bounds__(X3_THREADS, 1)
 k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
-                 int output_ch, const char* __restrict__ packed, float* __restrict__ out, float* __restrict__ act) {
+                 int output_ch, const char* __restrict__ packed, float* __restrict__ out, float* __restrict__ act,
+                 const uint32_t* __restrict__ marked) {
+    // `marked` (may be null): one word per 128-point tile; only tiles whose word is not zero are computed (the tiles the
+    // two-piece fp16 kernel handed back, mlp_fwd_f16x2.hip)
+    if (marked != nullptr && marked[blockIdx.x] == 0u) return;
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     char* ring = smem3;
     float* aux = reinterpret_cast<float*>(smem3 + RING3_BYTES);
@@ -419,6 +423,10 @@ static_assert(x3_lds_bytes(1) <= 160 * 1024 && x3_lds_bytes(0) <= 160 * 1024, "L
 
 }  // namespace
 
+int nerf_mlp_fwd_bf16x3_marked(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
+                               int output_ch, const void* packed, float* out, float* act, const uint32_t* tile_flags,
+                               void* stream);
+
 extern "C" {
 
 int64_t nerf_mlp_packed_bf16x3_bytes(int use_viewdirs) { return x3_packed_bytes(use_viewdirs); }
@@ -448,6 +456,15 @@ int nerf_gather_split3(const int32_t* table, const float* params, void* out, int
 
 int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
                         int output_ch, const void* packed, float* out, float* act, void* stream) {
+    return nerf_mlp_fwd_bf16x3_marked(n_pts, pts_per_ray, pts, viewdirs, use_viewdirs, output_ch, packed, out, act, nullptr, stream);
+}
+
+}  // extern "C"
+
+// the same launch restricted to the tiles marked in tile_flags (all tiles when it is null)
+int nerf_mlp_fwd_bf16x3_marked(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,
+                               int output_ch, const void* packed, float* out, float* act, const uint32_t* tile_flags,
+                               void* stream) {
     NERF_REQUIRE(n_pts >= 0, "nerf_mlp_fwd_bf16x3: n_pts=%lld", (long long)n_pts);
     if (n_pts == 0) return 0;
     NERF_REQUIRE(pts && packed && out, "nerf_mlp_fwd_bf16x3: null pointer");
@@ -462,12 +479,10 @@ int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), lds, as_stream(stream), n_pts, ppr, pts,
-                           vd, och, reinterpret_cast<const char*>(packed), out, act);
+                           vd, och, reinterpret_cast<const char*>(packed), out, act, tile_flags);
         return launched("nerf_mlp_fwd_bf16x3");
     };
     NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd_bf16x3: act must be 16-byte aligned");
     if (use_viewdirs) return act ? go(k_mlp_fwd_bf16x3<true, true>, pts_per_ray, viewdirs, 4) : go(k_mlp_fwd_bf16x3<true, false>, pts_per_ray, viewdirs, 4);
     return act ? go(k_mlp_fwd_bf16x3<false, true>, 1, nullptr, output_ch) : go(k_mlp_fwd_bf16x3<false, false>, 1, nullptr, output_ch);
 }
-
-}  // extern "C"

@@ -437,6 +437,36 @@ def mlp_forward_bf16x3(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], pack
     return out
 
 
+def pack_weights_f16x2(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    flat = _f32c(flat, "params")
+    assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
+    out = torch.empty(lib.nerf_mlp_packed_f16x2_bytes(int(use_viewdirs)), dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_pack_weights_f16x2(int(use_viewdirs), output_ch, flat.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def mlp_forward_f16x2(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed: torch.Tensor, packed_x3: Optional[torch.Tensor],
+                      use_viewdirs: bool, output_ch: int, pts_per_ray: int, act: Optional[torch.Tensor] = None,
+                      want_flags: bool = False):
+    """fp32-accurate inference on the fp16 matrix instruction: two fp16 pieces per operand, three products, fp32 sums;
+    tiles whose operands leave fp16's normal range are redone by the three-piece bf16 kernel (packed_x3; None = leave
+    them, for tests).  want_flags: also return the per-tile flag words."""
+    pts = _f32c(pts, "pts")
+    n_pts = pts.numel() // 3
+    out = torch.empty((n_pts, 4 if use_viewdirs else output_ch), dtype=torch.float32, device=pts.device)
+    if use_viewdirs:
+        viewdirs = _f32c(viewdirs, "viewdirs")
+        assert viewdirs.shape[0] * pts_per_ray == n_pts, (viewdirs.shape, pts_per_ray, n_pts)
+    tile = lib.nerf_mlp_f16x2_tile_points()
+    flags = torch.empty(((n_pts + tile - 1) // tile,), dtype=torch.int32, device=pts.device)
+    with torch.cuda.device(pts.device), _timed("mlp_fwd_f16x2" if act is None else "mlp_fwd_save", n_pts):
+        check(lib.nerf_mlp_fwd_f16x2(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
+                                     int(use_viewdirs), output_ch, packed.data_ptr(), _ptr(packed_x3), out.data_ptr(), _ptr(act),
+                                     flags.data_ptr(), _stream()))
+    return (out, flags) if want_flags else out
+
+
 def mlp_act_buffer(n_pts: int, use_viewdirs: bool, dev) -> torch.Tensor:
     return torch.empty(lib.nerf_mlp_act_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=dev)
 
@@ -595,7 +625,10 @@ def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_pe
             return mlp_forward_bf16(pts, viewdirs, model._packed_bf16(), model.use_viewdirs, model.output_ch, pts_per_ray)
         if dtype == "f32_mfma":
             return mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray)
-        return mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray)
+        if dtype == "bf16x3":
+            return mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(), model.use_viewdirs, model.output_ch, pts_per_ray)
+        return mlp_forward_f16x2(pts, viewdirs, model._packed_f16x2(), model._packed_bf16x3(), model.use_viewdirs, model.output_ch,
+                                 pts_per_ray)
     return _FusedMLP.apply(pts, viewdirs, model, pts_per_ray, need_grad, *params)
 
 

@@ -203,6 +203,12 @@ def create_nerf(args):
                                                                         embeddirs_fn=embeddirs_fn,
                                                                         netchunk=args.netchunk)
 
+    # the parameters move into their flat buffers NOW, before the optimiser (and any HIP graph or shadow copy a caller
+    # makes afterwards) takes their addresses: from here on data_ptr() of every parameter is stable
+    for net in (model, model_fine):
+        if net is not None and net.fused_arch():
+            net.adopt_flat()
+
     # (fused: the same Adam as one multi-tensor launch per step instead of seven)
     optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), fused=True)
 
@@ -438,8 +444,10 @@ def _save_frames(prefix, frames8):
 
 
 def _render_frames(rank, world, render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
-    """render_path for the driver: alone, or with the frames dealt to all ranks (every rank must call it; rank 0
-    writes the PNGs).  -> (rgbs, disps) numpy arrays, complete on every rank."""
+    """render_path for the driver: alone, or with the frames dealt to all ranks (every rank must call it).  With
+    savedir each rank writes the PNGs of the frames it rendered, so the directory must be on storage that all ranks
+    share (one node, or a shared file system); the complete sequence is returned on every rank either way.
+    -> (rgbs, disps) numpy arrays, complete on every rank."""
     from . import parallel
     if world == 1:
         return render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=gt_imgs, savedir=savedir,
@@ -578,7 +586,8 @@ def train(argv=None):
             path = os.path.join(basedir, expname, '{:06d}.tar'.format(i))
             save_checkpoint(path, global_step, render_kwargs_train, optimizer)
             print('Saved checkpoints at', path)
-        # the periodic renders involve every rank (frames are dealt round-robin); rank 0 writes the files
+        # the periodic renders involve every rank (frames are dealt round-robin); rank 0 writes the movie frames, every
+        # rank the test-set PNGs of the frames it rendered (the log directory is shared by the ranks of a node)
         if i % args.i_video == 0 and i > 0:
             with torch.no_grad():
                 rgbs, disps = _render_frames(rank, world, render_poses, hwf, K, args.chunk, render_kwargs_test)

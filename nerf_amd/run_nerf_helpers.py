@@ -148,11 +148,14 @@ class NeRF(nn.Module):
         self._flat_addrs = ()
         self._pack16x3 = None
         self._pack16x3b = None
+        self._pack16x2 = None
         # Which kernels evaluate the network:
-        #   'f32' (default)  fp32 accuracy on the bf16 matrix instruction: operands split exactly into three bf16 pieces,
-        #                    six piece products per product, fp32 sums (same error against fp64 as the fp32 instruction);
-        #                    rendering, training forward, backward-data and weight gradients
-        #   'bf16x3'         the same, spelled out
+        #   'f32' (default)  fp32 accuracy on the 16-bit matrix instructions.  No-grad queries (rendering): two fp16 pieces
+        #                    per operand, three piece products per product, fp32 sums; tiles of 128 points whose operands
+        #                    leave fp16's normal range are redone on the three-piece kernel.  Training (forward,
+        #                    backward-data, weight gradients): operands split exactly into three bf16 pieces, six piece
+        #                    products per product, fp32 sums.  Either measures the error of the fp32 instruction against fp64
+        #   'bf16x3'         the three-piece kernels everywhere, rendering included
         #   'f32_mfma'       the fp32 matrix instruction, rendering and all of training
         #   'bf16'           no-grad queries only, reduced precision: bf16 operands, fp32 sums, raw outputs within ~1e-2
         #                    of their scale (training with this setting runs the 'f32' kernels)
@@ -197,8 +200,16 @@ class NeRF(nn.Module):
         key = (_OPT_STEPS[0],) + tuple(p._version for p in params)
         if self._pack_key != key:
             self._pack_key = key
-            self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = None
+            self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = self._pack16x2 = None
         return store
+
+    def adopt_flat(self) -> None:
+        """Move the parameters into the module's flat buffer now (see _flat) instead of at the first query: call it after
+        `.to(device)` and BEFORE anything keeps a parameter's address or storage -- a HIP graph, an EMA or shadow copy
+        made through `p.data`, an external loader holding data_ptr() -- because adoption rebinds every `.data` to a view
+        of the new buffer and whoever still points at the old storage is not told.  create_nerf does this for the models
+        it builds; a module constructed by hand adopts at its first query."""
+        self._flat()
 
     def invalidate_packs(self) -> None:
         """Forget every packed weight stream; the next query rebuilds them from the parameters.  The cache key is each
@@ -230,6 +241,13 @@ class NeRF(nn.Module):
             else:
                 self._pack16x3 = ops.pack_weights_bf16x3(flat, self.use_viewdirs, self.output_ch)
         return self._pack16x3
+
+    def _packed_f16x2(self):
+        """Stream of fp16 pairs of the no-grad query."""
+        flat = self._flat()
+        if self._pack16x2 is None:
+            self._pack16x2 = ops.pack_weights_f16x2(flat, self.use_viewdirs, self.output_ch)
+        return self._pack16x2
 
     def _packed_bwd_bf16x3(self):
         self._flat()

@@ -337,9 +337,11 @@ def test_mlp_forward_ragged_sizes_and_peaky_weights(device):
             raw32 = ops.mlp_forward_encoded(x_enc, m._packed(), True, 5)
             raw16 = ops.mlp_forward_x4(flat_pts, dirs, m._packed_x4(), True, 5, s)
             raw3 = ops.mlp_forward_bf16x3(flat_pts, dirs, m._packed_bf16x3(), True, 5, s)
+            raw2 = ops.mlp_forward_f16x2(flat_pts, dirs, m._packed_f16x2(), m._packed_bf16x3(), True, 5, s)
         close(raw32.reshape(n, s, 4), want, 3e-5, 3e-6 * max(1.0, scale), f"mlp on pre-encoded inputs {n}x{s}")
         close(raw16.reshape(n, s, 4), want, 3e-5, 3e-6 * max(1.0, scale), f"mlp fp32 matrix instruction {n}x{s}")
-        close(raw3.reshape(n, s, 4), raw, 0, 0, f"mlp split-operand kernel {n}x{s} (same kernel as the query)")
+        close(raw3.reshape(n, s, 4), want, 3e-5, 3e-6 * max(1.0, scale), f"mlp three-piece bf16 kernel {n}x{s}")
+        close(raw2.reshape(n, s, 4), raw, 0, 0, f"mlp two-piece fp16 kernel {n}x{s} (same kernel as the query)")
         for dtype in ("f32", "f32_mfma"):
             m.mlp_dtype = dtype
             raw_train = qf(pts.to(device), vd.to(device), m)
@@ -349,8 +351,8 @@ def test_mlp_forward_ragged_sizes_and_peaky_weights(device):
 
 
 def test_split_operand_kernel_is_as_accurate_as_the_fp32_matrix_instruction(device):
-    """The default no-grad kernel rebuilds every fp32 product from exact three-way bf16 splits (six piece products, fp32
-    sums).  Against an fp64 evaluation its error is that of the fp32 matrix-instruction kernel (within 1.5x, or below
+    """The three-piece kernel (mlp_dtype = 'bf16x3'; training forward of the default) rebuilds every fp32 product from
+    exact three-way bf16 splits (six piece products, fp32 sums).  Against an fp64 evaluation its error is that of the fp32 matrix-instruction kernel (within 1.5x, or below
     1e-6 of the outputs' scale), with and without the view branch, on random and on peaky weights; and a model told to
     use the fp32 matrix instruction (mlp_dtype = 'f32_mfma') renders within the usual summation-order distance."""
     from nerf_amd import ops
@@ -375,7 +377,7 @@ def test_split_operand_kernel_is_as_accurate_as_the_fp32_matrix_instruction(devi
         with torch.no_grad():
             r3 = ops.mlp_forward_bf16x3(flat, dirs, m._packed_bf16x3(), use_vd, 5, s).cpu().double().reshape(truth.shape)
             r32 = ops.mlp_forward_x4(flat, dirs, m._packed_x4(), use_vd, 5, s).cpu().double().reshape(truth.shape)
-            assert m.mlp_dtype == 'f32'
+            m.mlp_dtype = 'bf16x3'
             default = qf(pts.to(device), dirs, m)
             m.mlp_dtype = 'f32_mfma'
             forced = qf(pts.to(device), dirs, m)

@@ -1,6 +1,7 @@
-"""Times the forward kernels on one 32768-ray fine chunk (4.19 M points): python3 tools/time_fwd.py [x3|x4|save] [reps]
-(NERF_HIP_LIB selects a variant build).  x3: the split-operand inference kernel (default); x4: the fp32 matrix
-instruction; save: the split-operand training forward that stores activations (2.1 M points)."""
+"""Times the forward kernels on one 32768-ray fine chunk (4.19 M points): python3 tools/time_fwd.py [x2|x2only|x3|x4|save] [reps]
+(NERF_HIP_LIB selects a variant build).  x2: the two-piece fp16 inference kernel followed by the three-piece kernel on
+the tiles it marked (default of rendering); x2only: its first launch alone; x3: the three-piece bf16 kernel; x4: the fp32
+matrix instruction; save: the three-piece training forward that stores activations (2.1 M points)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
@@ -19,8 +20,12 @@ ref = ops.mlp_forward_x4(pts, vd, m._packed_x4(), True, 5, S)
 def run():
     if which == "x4":
         return ops.mlp_forward_x4(pts, vd, m._packed_x4(), True, 5, S)
+    if which in ("x2", "x2only"):
+        return ops.mlp_forward_f16x2(pts, vd, m._packed_f16x2(), m._packed_bf16x3() if which == "x2" else None, True, 5, S)
     return ops.mlp_forward_bf16x3(pts, vd, m._packed_bf16x3(), True, 5, S, act)
 out = run()
+if which.startswith("x2"):
+    print("marked tiles:", int(ops.mlp_forward_f16x2(pts, vd, m._packed_f16x2(), None, True, 5, S, want_flags=True)[1].sum()), "of", n_rays * S // 128)
 print("max diff vs the fp32 matrix instruction", (ref - out).abs().max().item(), "checksum", float(out.double().sum()))
 for rep in range(3):
     torch.cuda.synchronize()
