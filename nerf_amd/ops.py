@@ -586,6 +586,10 @@ class _FusedMLP(torch.autograd.Function):
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
         if pts_per_ray == 0:      # pre-encoded rows (NeRF.forward(x)); every backward reads what this forward saves
             out = mlp_forward_encoded(pts, model._packed(), model.use_viewdirs, model.output_ch, act)
+        elif kind == "bf16x3" and getattr(model, "mlp_dtype", "f32") != "bf16x3":
+            # the two-piece fp16 kernel, saving activations; marked tiles are redone (and re-saved) by the three-piece kernel
+            out = mlp_forward_f16x2(pts, viewdirs, model._packed_f16x2(), model._packed_bf16x3(with_bwd=need_grad),
+                                    model.use_viewdirs, model.output_ch, pts_per_ray, act)
         elif kind == "bf16x3":
             out = mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(with_bwd=need_grad), model.use_viewdirs, model.output_ch,
                                      pts_per_ray, act)

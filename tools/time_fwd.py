@@ -27,12 +27,16 @@ out = run()
 if which.startswith("x2"):
     print("marked tiles:", int(ops.mlp_forward_f16x2(pts, vd, m._packed_f16x2(), None, True, 5, S, want_flags=True)[1].sum()), "of", n_rays * S // 128)
 print("max diff vs the fp32 matrix instruction", (ref - out).abs().max().item(), "checksum", float(out.double().sum()))
+from nerf_amd import gpustat
 for rep in range(3):
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        run()
-    b.record(); torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / reps
-    print(f"{os.environ.get('NERF_HIP_LIB', 'product')} {which}: {ms:.3f} ms, {n_rays * S * 1186816 / ms / 1e9:.1f} TFLOP/s algorithmic", flush=True)
+    with gpustat.sampler_for(0, 0.02) as stat:
+        a.record()
+        for _ in range(reps if rep < 2 else 8 * reps):     # the last block is long enough for the power reading to settle
+            run()
+        b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / (reps if rep < 2 else 8 * reps)
+    st = stat.summary()
+    print(f"{os.environ.get('NERF_HIP_LIB', 'product')} {which}: {ms:.3f} ms, {n_rays * S * 1186816 / ms / 1e9:.1f} TFLOP/s algorithmic, "
+          f"{st['clock_ghz_mean']} GHz {st['power_w_mean']} W ({st['samples']} samples)", flush=True)
