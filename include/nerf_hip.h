@@ -15,7 +15,12 @@
  *     nerf_last_error() on the calling thread; argument errors are detected before any launch;
  *   - tensors are dense row-major with the shapes given; "rays" is the packed per-ray record of
  *     upstream render(): [o(3) d(3) near far viewdir(3)] with a caller-given row stride in floats;
- *   - thread-compatible: no global mutable state besides the thread-local error string.
+ *   - thread-compatible: the error string is thread-local; the only other state the library keeps is per-device
+ *     set-up it makes on first use and guards with a mutex (which kernels have been given their LDS limit, the
+ *     compute-unit count, the device address of nerf_mlp_bwd_bf16x3_static's built-in workspace);
+ *   - graph capture: an entry point that has run once on a device makes no runtime call besides hipGetDevice, stream
+ *     operations and kernel launches when it runs again, so make one eager call per entry point and device before
+ *     capturing (the first call sets LDS limits with hipFuncSetAttribute and may load code lazily).
  */
 #ifndef NERF_HIP_H
 #define NERF_HIP_H
@@ -290,7 +295,9 @@ int nerf_linear_bwd_weights(int64_t n, int n_in, int n_out, const float* dy, int
  * the workspace: the dY rows and partial-gradient slabs live in an array the library's code object holds on every
  * device it is loaded on (about 40 MB per device until the process ends).  Limits: n_pts <= NERF_STATIC_BWD_MAX_PTS
  * per call, otherwise NERF_E_ARG; the call allocates nothing; every call on one device shares that device's array,
- * so calls that overlap on one device (two streams, two threads) race -- serialise them. */
+ * so calls that overlap on one device (two streams, two threads) race -- serialise them.  The FIRST call on a device
+ * looks up the array's device address (hipGetSymbolAddress, which may load the code object and synchronise) and sets
+ * LDS limits: make it outside graph capture; later calls only enqueue. */
 #define NERF_STATIC_BWD_MAX_PTS 2048
 int64_t nerf_mlp_bwd_static_max_points(void);
 int nerf_mlp_bwd_bf16x3_static(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,

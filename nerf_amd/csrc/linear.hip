@@ -108,14 +108,45 @@ __global__ void __launch_bounds__(256) k_sum_slices(const float* __restrict__ pa
     }
 }
 
-// dy * (y > 0): the gradient entering a ReLU layer's products
+// The gradient entering a ReLU layer's products: zero where the saved output is <= 0, dy elsewhere -- a NaN output lets
+// dy through, as torch's threshold_backward does (its test is `output <= 0`).
 __global__ void __launch_bounds__(256) k_relu_grad(int64_t n, const float* __restrict__ dy, const float* __restrict__ y,
                                                    float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+        out[i] = y[i] <= 0.0f ? 0.0f : dy[i];
 }
 
-__global__ void k_one(float* p) { *p = 1.0f; }
+// Column sums of dy [n, n_out] (the bias gradient) accumulated in fp64: a block of 16 x 64 threads sums the rows of one
+// slice for 64 columns, 16 rows at a time, then across its 16 row lanes; the slice's sum is left as a (high, low) pair of
+// floats.  Accumulating in fp64 keeps the error at one fp32 rounding of the result whatever the row count (the matrix
+// kernel used before summed each slice's ~1000 rows one after the other in fp32).
+constexpr int CS_ROWS = 16;
+__global__ void __launch_bounds__(64 * CS_ROWS) k_col_sum(const float* __restrict__ dy, int64_t ldy, int64_t n, int n_out,
+                                                          int64_t rows_per_slice, float* __restrict__ part) {
+    __shared__ double red[CS_ROWS][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice, r1 = r0 + rows_per_slice < n ? r0 + rows_per_slice : n;
+    double s = 0.0;
+    if (col < n_out)
+        for (int64_t r = r0 + rl; r < r1; r += CS_ROWS) s += (double)dy[r * ldy + col];
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && col < n_out) {
+#pragma unroll
+        for (int k = 1; k < CS_ROWS; ++k) s += red[k][c];
+        const float hi = (float)s;
+        float* dst = part + 2 * ((int64_t)blockIdx.y * n_out + col);
+        dst[0] = hi;
+        dst[1] = (float)(s - (double)hi);
+    }
+}
+__global__ void __launch_bounds__(256) k_col_finish(const float* __restrict__ part, int slices, int n_out, float* __restrict__ db) {
+    for (int col = blockIdx.x * blockDim.x + threadIdx.x; col < n_out; col += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int z = 0; z < slices; ++z) s += (double)part[2 * ((int64_t)z * n_out + col)] + (double)part[2 * ((int64_t)z * n_out + col) + 1];
+        db[col] = (float)s;
+    }
+}
 
 int gemm(const Operand& A, const Operand& B, int64_t K, int slices, const float* bias, int relu, float* C, int64_t ldc,
          int64_t slice_stride, hipStream_t stream, const char* who) {
@@ -185,7 +216,6 @@ int nerf_linear_bwd_weights(int64_t n, int n_in, int n_out, const float* dy, int
     if (slices > WSLICES) slices = WSLICES;
     float* part_w = workspace;
     float* part_b = workspace + (int64_t)WSLICES * wn;
-    float* one = part_b + (int64_t)WSLICES * n_out;
     const Operand A{dy, 1, ldy, n_out};                   // A(i, k) = dy[k][i]
     const Operand Bx{x, 1, ldx, n_in};                    // B(j, k) = x[k][j]
     int rc = gemm(A, Bx, n, slices, nullptr, 0, part_w, n_in, wn, stream, "nerf_linear_bwd_weights");
@@ -194,11 +224,15 @@ int nerf_linear_bwd_weights(int64_t n, int n_in, int n_out, const float* dy, int
                        part_w, wn, slices, wn, dw);
     rc = launched("nerf_linear_bwd_weights (sum)");
     if (rc || !db) return rc;
-    hipLaunchKernelGGL(k_one, dim3(1), dim3(1), 0, stream, one);
-    const Operand B1{one, 0, 0, 1};                       // B(0, k) = 1
-    rc = gemm(A, B1, n, slices, nullptr, 0, part_b, 1, n_out, stream, "nerf_linear_bwd_weights (bias)");
+    // db = column sums of dy, in fp64, over at most WSLICES / 2 slices (a slice leaves two floats per column)
+    int bslices = (int)((n + 4095) / 4096);
+    if (bslices > WSLICES / 2) bslices = WSLICES / 2;
+    const int64_t rows_per_slice = (n + bslices - 1) / bslices;
+    hipLaunchKernelGGL(k_col_sum, dim3((unsigned)((n_out + 63) / 64), (unsigned)bslices), dim3(64 * CS_ROWS), 0, stream, dy, ldy, n,
+                       n_out, rows_per_slice, part_b);
+    rc = launched("nerf_linear_bwd_weights (bias)");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sum_slices, dim3(1), dim3(256), 0, stream, part_b, (int64_t)n_out, slices, (int64_t)n_out, db);
+    hipLaunchKernelGGL(k_col_finish, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, part_b, bslices, n_out, db);
     return launched("nerf_linear_bwd_weights (bias sum)");
 }
 

@@ -403,8 +403,7 @@ static int run_dw(int64_t ldp, int use_viewdirs, int output_ch, const ParamOffse
         cost[nt] = 5; tk.t[nt++] = a;
     }
     tk.n = nt;
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int n_cu = compute_units();
     if (n_cu < nt) n_cu = nt;
     const int64_t nchunks = ldp / KT;
     assign_splits(tk, cost, nchunks, n_cu);
@@ -417,7 +416,7 @@ static int run_dw(int64_t ldp, int use_viewdirs, int output_ch, const ParamOffse
     // slab entries no task covers (parameters that receive no gradient) must read as zero in the reduction
     e = hipMemsetAsync(slabs, 0, (size_t)nslabs * slab * sizeof(float), stream);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_LDS_BYTES);
+    e = lds_limit_once(reinterpret_cast<const void*>(k_dw_gemm), DW_LDS_BYTES);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k_dw_gemm, dim3(n_wg), dim3(DW_THREADS), DW_LDS_BYTES, stream, tk, nchunks,
                        (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab);

@@ -83,17 +83,8 @@ __device__ __forceinline__ void layer_x3b(Stream3& st, int lane, int g, const ch
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
             if constexpr (I % SLABT == 0) {
-#ifdef X3_STORE_BLIND   // (ablation build: the wait as it was before the stores were counted)
-                cur = st.advance(lane);
-#else
                 cur = st.template advance<(I > 0) ? x3_stores_since_open(I, NKS) : 0>(lane);
-#endif
             }
-#ifdef X3_SPREAD   // one request of the slab after next behind each of the first six triples of a slab
-            if constexpr (I % SLABT >= 1 && I % SLABT <= WAVE_BLOCKS3) {
-                if (st.next + 1 < st.nslabs) st.template fetch_block<I % SLABT - 1>(st.next + 1);
-            }
-#endif
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 abuf[I % (DEPTH + 1)][s] = *reinterpret_cast<const bf16x8*>(cur + (I % SLABT) * TRIPLE_BYTES + s * 1024);
@@ -315,8 +306,7 @@ int launch_bwd_data_x3(int64_t n_pts, int use_viewdirs, int output_ch, const flo
                        const void* packed_x3, const void* packed_bwd_x3, float* scratch, hipStream_t stream) {
     const int64_t blocks = padded_points(n_pts) / TILE_PTS;
     auto go = [&](auto kernel, int och) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)X3B_LDS_BYTES);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), X3B_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), X3B_LDS_BYTES, stream, n_pts, och, d_out, act,
                            reinterpret_cast<const char*>(packed_x3), reinterpret_cast<const char*>(packed_bwd_x3), scratch);

@@ -218,14 +218,12 @@ int launch_bwd_data_x4(int64_t n_pts, int use_viewdirs, int output_ch, const flo
     const int64_t blocks = padded_points(n_pts) / TILE_PTS;
     hipError_t e;
     if (use_viewdirs) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data_x4<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)X4B_LDS_BYTES);
+        e = lds_limit_once(reinterpret_cast<const void*>(k_mlp_bwd_data_x4<true>), X4B_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_x4: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k_mlp_bwd_data_x4<true>, dim3((unsigned)blocks), dim3(X4_THREADS), X4B_LDS_BYTES, stream, n_pts, 4, d_out,
                            act, packed_x4, packed_bwd_x4, scratch);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_data_x4<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)X4B_LDS_BYTES);
+        e = lds_limit_once(reinterpret_cast<const void*>(k_mlp_bwd_data_x4<false>), X4B_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_x4: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k_mlp_bwd_data_x4<false>, dim3((unsigned)blocks), dim3(X4_THREADS), X4B_LDS_BYTES, stream, n_pts,
                            output_ch, d_out, act, packed_x4, packed_bwd_x4, scratch);

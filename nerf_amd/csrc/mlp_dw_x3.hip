@@ -20,15 +20,11 @@
 // loads 7.7 ms at 2.03 GHz (84 % of the matrix pipe's cycles busy); loads and split alone 8.0 ms at 2.19 GHz (3.9 TB/s):
 // the board's power limit, not latency or issue slots, bounds the kernel -- the two parts add up instead of overlapping,
 // whatever the prefetch depth (one or two stages in registers, or a seven-deep LDS-DMA ring: 12.3-13.5 ms).
-// Switches for such ablation builds (tools/ab_dw.sh; the product defines none): DWX_NO_LOAD (stages re-use their first
-// loads), DWX_NO_MFMA, DWX_STREAM_ONLY (no LDS image: loads, split and bias sums only), DWX_MAP16 (a wave's load covers
-// 4 row groups x 16 points = 256-byte runs instead of 8 x 8 = 128-byte ones: the stream-only build reads 3.42 TB/s
-// either way, so the run length is not what holds the loads back), DWX_SETS=3 (three register sets = three stages in
-// flight: loads and split alone go from 3.9 to 4.4 TB/s, but the 256 x 256 task already holds 248 of its 256 registers
-// and spills 50-88 of them with a third set, 18.3 ms), DWX_RAW (the third stage in flight through an LDS slot filled by
-// LDS-DMA instead of registers: 12.7 ms against 12.3, so a deeper queue of loads is not what the full kernel lacks
-// either), DWX_A_SINGLE (row-tile fragments not read ahead, 12 registers fewer: 12.4 ms), DWX_ONLY_K0 (register-pressure
-// probe), DWX_PLAIN_LOADS (temporal loads: 12.5 ms).
+// Variants that were measured and not kept (same 1.57 M points): a wave's load covering 256-byte instead of 128-byte runs
+// (loads and split alone read 3.42 TB/s either way); three register sets = three stages in flight (loads and split alone
+// go from 3.9 to 4.4 TB/s, but the 256 x 256 task already holds 248 of its 256 registers and spills 50-88 of them:
+// 18.3 ms); a third stage in flight through an LDS slot filled by LDS-DMA (12.7 ms: a deeper queue of loads is not
+// what the full kernel lacks); row-tile fragments not read ahead (12.4 ms); temporal instead of non-temporal loads (12.5 ms).
 // Bias gradients are fp32 row sums of dY taken in the staging path.  Partial results go to per-slice slabs that a last
 // kernel sums in fixed order (bitwise reproducible, no float atomics).
 #include "common.hpp"
@@ -48,16 +44,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int DWX_THREADS = 512;
 constexpr int SP = 16;                 // points per stage
 constexpr int MAX_LOADS = 5;
-#if defined(DWX_RAW)     // (ablation build: a third stage in flight through an LDS slot filled by LDS-DMA, tasks of <= 4 loads)
-constexpr int NSETS = 3;
-constexpr bool RAW_SLOT = true;
-#elif defined(DWX_SETS)  // (ablation builds: three register sets of loads = three stages in flight)
-constexpr int NSETS = DWX_SETS;
-constexpr bool RAW_SLOT = false;
-#else
 constexpr int NSETS = 2;
 constexpr bool RAW_SLOT = false;
-#endif
 static_assert(NSETS == 2 || NSETS == 3, "the stage loop is written for two or three sets");
 
 // What a kind of task looks like to a workgroup.  The LDS image holds 128 * NL operand rows per point: the dY rows
@@ -136,11 +124,7 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     }
 
     // ---- staging map: thread -> (row group 32 k + rgi, point pt) of every load k
-#ifdef DWX_MAP16     // (ablation build: 256-byte runs per row group and instruction instead of 128-byte ones)
-    const int pt = lane & 15, rgi = 4 * wave + (lane >> 4);
-#else
     const int pt = 8 * (wave & 1) + (lane & 7), rgi = 8 * (wave >> 1) + (lane >> 3);
-#endif
     const float* gsrc[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -157,11 +141,7 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         rd[r] = p_ * Im::PS + 8 * swz(4 * (g & 1) + (lane & 3), p_);
     }
     const int off_a = 64 * a_tile0, off_b = 64 * (K::A_TILES + b_tile0);
-#ifdef DWX_STREAM_ONLY
-    auto frag = [&](const char* img, int off) { bf16x8 z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.0f; return z; };
-#else
     auto frag = [&](const char* img, int off) { return cat8(tr16(img + rd[0] + off), tr16(img + rd[1] + off)); };
-#endif
 
     // ---- loads: two register sets, the stages after next; set (s - c0) & 1 holds stage s
     constexpr bool RAW = RAW_SLOT && NL <= 4;             // set 2 = the LDS slot behind the two images
@@ -176,11 +156,7 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
                                              (__attribute__((address_space(3))) void*)(raw_mine + k * 8192), 16, 0, 0);
             return;
         }
-#ifdef DWX_PLAIN_LOADS   // (ablation build)
-        stage[SET][k] = *reinterpret_cast<const f32x4*>(gsrc[k] + off);
-#else                    // every operand byte is read once: non-temporal loads (+1.2 % on the kernel, same-box A/B)
         stage[SET][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gsrc[k] + off));
-#endif
     };
     float bsum[NBIAS][4];
 #pragma unroll
@@ -205,17 +181,13 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
             h[e] = a; m[e] = b; l[e] = c;
         }
         char* dst = img + wr_off + 256 * k;
-#ifdef DWX_STREAM_ONLY
-        asm volatile("" ::"v"(h), "v"(m), "v"(l), "v"(dst));
-#else
         *reinterpret_cast<bf16x4*>(dst) = h;
         *reinterpret_cast<bf16x4*>(dst + Im::PL) = m;
         *reinterpret_cast<bf16x4*>(dst + 2 * Im::PL) = l;
-#endif
         if constexpr (k < NBIAS) {   // (no branch: the compiler's load bookkeeping stays exact in straight-line code)
-            const float live = chunk < c1 ? 1.0f : 0.0f;
+            const bool live = chunk < c1;   // (a select, not a product with 0: an infinite dY of a repeated chunk must not turn into NaN)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bsum[k][e] = fmaf(v[e], live, bsum[k][e]);
+            for (int e = 0; e < 4; ++e) bsum[k][e] += live ? v[e] : 0.0f;
         }
     };
 
@@ -248,11 +220,7 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int s = 0; s < 3; ++s) B[j][s] = frag(cur + s * Im::PL, off_b + 64 * j);
-#ifdef DWX_A_SINGLE   // (ablation / three-set builds: one set of row-tile fragments, read right before their products)
-        constexpr int ABUF = 1;
-#else
         constexpr int ABUF = 2;                          // a row tile's fragments, read one tile ahead
-#endif
         bf16x8 A[ABUF][3];
         auto read_a = [&]<int i>() {
 #pragma unroll
@@ -263,22 +231,18 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
             if constexpr (ABUF == 1) read_a.template operator()<i>();
             else if constexpr (i + 1 < TM) read_a.template operator()<i + 1>();
             __builtin_amdgcn_sched_barrier(0);
-#ifndef DWX_NO_MFMA
             // (idle waves of a head task multiply too: what they read is finite, and they store nothing)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 6; ++q)              // (dY piece, input piece), smallest products first
                     acc[i][j] = mfma32(A[i % ABUF][PROD_W[q]], B[j][PROD_X[q]], acc[i][j]);
-#endif
             // staging of stage c + 1 behind the matrix work: load k is split when row tile group(k) multiplies, and
             // its registers are re-requested for stage c + 3
             static_for<NL>([&]<int k>() {
                 if constexpr (((k + 1) * TM - 1) / NL == i) {
                     commit.template operator()<S, k>(nxt, c + 1);
-#ifndef DWX_NO_LOAD
                     request.template operator()<S, k>(c + 1 + NSETS);
-#endif
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -355,11 +319,9 @@ k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __res
     float* slab = slabs + (int64_t)split * slab_stride;
     switch (task.kind) {
         case 0: dwx_loop<0>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
-#ifndef DWX_ONLY_K0   // (register-pressure probe: only the 256 x 256 task compiled)
         case 1: dwx_loop<1>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
         case 2: dwx_loop<2>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
         default: dwx_loop<3>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
-#endif
     }
 }
 
@@ -419,8 +381,7 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
         cost[nt] = 6; tk.t[nt++] = a;
     }
     tk.n = nt;
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int n_cu = compute_units();
     if (n_cu < nt) n_cu = nt;
     const int64_t nchunks = ldp / SP;
     // slices per task: one more slice to the task whose slices are longest until the launch is one workgroup per CU
@@ -463,7 +424,7 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
     }
     const size_t lds = DWX_LDS_BYTES;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = lds_limit_once(reinterpret_cast<const void*>(k_dw_x3), lds);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k_dw_x3, dim3(n_wg), dim3(DWX_THREADS), lds, stream, tk, nchunks,
                        (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab);

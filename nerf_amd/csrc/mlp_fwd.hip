@@ -278,7 +278,7 @@ int nerf_mlp_fwd_encoded(int64_t n_pts, const float* x, int use_viewdirs, int ou
     NERF_REQUIRE(!act || (reinterpret_cast<uintptr_t>(act) & 15) == 0, "nerf_mlp_fwd_encoded: act must be 16-byte aligned");
     const int width = IN_PTS + (use_viewdirs ? IN_DIRS : 0);
     auto go = [&](auto kernel, int och) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_BYTES);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), FWD_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_encoded: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), FWD_LDS_BYTES, as_stream(stream), n_pts, width, x,
                            static_cast<const float*>(nullptr), och, packed_fwd, out, act);

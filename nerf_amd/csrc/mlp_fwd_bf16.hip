@@ -337,8 +337,7 @@ int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const fl
     const int64_t blocks = (n_pts + WG_PTS - 1) / WG_PTS;
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_bf16: n_pts=%lld too large for one launch", (long long)n_pts);
     auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)FWD16_LDS_BYTES);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), FWD16_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS16), FWD16_LDS_BYTES, as_stream(stream), n_pts, ppr, pts,
                            vd, och, reinterpret_cast<const char*>(packed_bf16), out);

@@ -70,9 +70,6 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
     auto load_bias = [&]<int TO>() { bnext = *reinterpret_cast<const f32x4*>(bp + 16 * TO); };
     auto piece = [&]<int TP, int K>() {           // K = 4 * column tile + register: one value of the tile per piece
         constexpr int ct = K >> 2, r = K & 3;
-#ifdef X3_NO_EPI
-        if constexpr (NHEAD == 0 && !SAVE) return;
-#endif
         float v = acc[TP & 1][ct][r];
         if constexpr (!BIAS_INIT) v += bp[16 * TP + r];
         v = max_keep_nan(v, lo);
@@ -101,20 +98,8 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
     static_for<NB + DEPTH>([&]<int I>() {
         if constexpr (I < NB) {
             if constexpr (I % SLABT == 0) {
-#ifdef X3_STORE_BLIND   // (ablation build: the wait as it was before the stores were counted)
-                cur = st.advance(lane);
-#else
                 cur = st.template advance<(SAVE && I > 0) ? x3_stores_since_open(I, NKS) : 0>(lane);
-#endif
             }
-#ifdef X3_SPREAD   // one request of the slab after next behind each of the first six triples of a slab
-            if constexpr (I % SLABT >= 1 && I % SLABT <= WAVE_BLOCKS3) {
-                if (st.next + 1 < st.nslabs) st.template fetch_block<I % SLABT - 1>(st.next + 1);
-            }
-#endif
-#ifdef X3_NO_AREAD
-            if constexpr (I < DEPTH + 1)
-#endif
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 abuf[I % (DEPTH + 1)][s] = *reinterpret_cast<const bf16x8*>(cur + (I % SLABT) * TRIPLE_BYTES + s * 1024);
@@ -201,7 +186,6 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
         park(2 * ct + 0, e);
         park(2 * ct + 1, e + 8);
         const int pw = wave * WAVE_PTS + ct * 16 + (lane & 15);   // point inside the tile
-#ifndef X3_NO_ENC_SAVE   // (ablation build: what the 4-byte stores of the encodings cost)
         if constexpr (SAVE) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -209,7 +193,6 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
                 tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid[ct] && f >= 0) ? e[q] : 0.0f;
             }
         }
-#endif
         if (VIEWDIRS) {
             const int64_t ray = pl / pts_per_ray;
             const float v0 = viewdirs[ray * 3 + 0], v1 = viewdirs[ray * 3 + 1], v2 = viewdirs[ray * 3 + 2];
@@ -223,7 +206,6 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
             dd[6] = g == 0 ? v0 : (g == 1 ? v2 : 0.0f);
             dd[7] = g == 0 ? v1 : 0.0f;
             park(2 * NCT + ct, dd);
-#ifndef X3_NO_ENC_SAVE
             if constexpr (SAVE) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -233,7 +215,6 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
                     tile[(row >> 2) * GROUP_FLOATS + pw * 4 + (row & 3)] = (valid[ct] && f >= 0) ? dd[q] : 0.0f;
                 }
             }
-#endif
         }
     }
 
@@ -476,7 +457,7 @@ int nerf_mlp_fwd_bf16x3_marked(int64_t n_pts, int pts_per_ray, const float* pts,
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_bf16x3: n_pts=%lld too large for one launch", (long long)n_pts);
     auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
         const size_t lds = x3_lds_bytes(use_viewdirs);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), lds, as_stream(stream), n_pts, ppr, pts,
                            vd, och, reinterpret_cast<const char*>(packed), out, act, tile_flags);

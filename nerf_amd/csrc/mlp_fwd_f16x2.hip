@@ -497,7 +497,7 @@ int nerf_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* pts, const f
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_f16x2: n_pts=%lld too large for one launch", (long long)n_pts);
     auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
         const size_t lds = x2_lds_bytes(use_viewdirs);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_f16x2: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X2_THREADS), lds, as_stream(stream), n_pts, ppr, pts,
                            vd, och, reinterpret_cast<const char*>(packed), out, act, tile_flags);

@@ -309,8 +309,7 @@ int nerf_mlp_fwd_x4(int64_t n_pts, int pts_per_ray, const float* pts, const floa
     const int64_t blocks = (n_pts + X4_WG_PTS - 1) / X4_WG_PTS;
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_mlp_fwd_x4: n_pts=%lld too large for one launch", (long long)n_pts);
     auto go = [&](auto kernel, int ppr, const float* vd, int och) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)X4_LDS_BYTES);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), X4_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_x4: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X4_THREADS), X4_LDS_BYTES, as_stream(stream), n_pts, ppr, pts, vd,
                            och, packed_x4, out, act);

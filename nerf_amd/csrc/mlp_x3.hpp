@@ -37,15 +37,6 @@ struct Stream3 {
     int next, nslabs;
     // One address pair per slab: the instruction's immediate offset moves BOTH the global and the LDS address, so the six
     // 1 KiB blocks of a wave are offsets -2048 .. 3072 from the middle of its share (the field is 13 bits, signed).
-#ifdef X3_FETCH_OLD
-    __device__ __forceinline__ void fetch(int slab) {
-        const char* src = g + (int64_t)slab * SLAB3_BYTES;
-        char* dst = mine + (slab % RING_DEPTH) * SLAB3_BYTES;
-#pragma unroll
-        for (int b = 0; b < WAVE_BLOCKS3; ++b)
-            glds16(reinterpret_cast<const float*>(src + b * 1024), reinterpret_cast<float*>(dst + b * 1024));
-    }
-#else
     __device__ __forceinline__ void fetch(int slab) {
         const char* src = g + (int64_t)slab * SLAB3_BYTES + 2048;
         char* dst = mine + (slab % RING_DEPTH) * SLAB3_BYTES + 2048;
@@ -61,7 +52,6 @@ struct Stream3 {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, b * 1024 - 2048, 0);
     }
-#endif
     // Opens slab `next`: its loads (issued two slabs ago) have landed -- those of slab next+1 may still be in flight,
     // loads return in order -- and every wave is done with slab next-1, whose buffer the request for slab next+2 reuses.
     // (One request per triple among the MFMAs, instead of six here, measured 3.6 % slower.)
@@ -73,20 +63,14 @@ struct Stream3 {
     template <int STORES = 0> __device__ __forceinline__ const char* advance(int lane) {
         static_assert(WAVE_BLOCKS3 == 6, "the wait below leaves one slab's loads of this wave in flight");
         static_assert(STORES >= 0 && 6 + STORES <= 63, "vmcnt is a six-bit field");
-#ifndef X3_NO_WAIT       // (ablation builds)
         if (next + 1 < nslabs) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + STORES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         // a bare barrier: __syncthreads() would first wait for ALL of this wave's loads, the next slab's included.  The
         // buffer requested below was last read a whole slab ago (reads run three triples ahead of their MFMAs), so no
         // LDS read of it is still pending in any wave.
-#ifndef X3_NO_BARRIER    // (ablation builds: tools/ab_x3.sh)
         asm volatile("s_barrier" ::: "memory");
-#endif
         const char* cur = ring + (next % RING_DEPTH) * SLAB3_BYTES + lane * 16;
-#if !defined(X3_SPREAD) && !defined(X3_NO_FETCH)
         if (next + 2 < nslabs) fetch(next + 2);
-#endif
         ++next;
         return cur;
     }

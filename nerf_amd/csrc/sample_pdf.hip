@@ -291,8 +291,7 @@ int nerf_sample_fine(int64_t n, int Sc, int Si, const float* z, const float* wei
                                                   (size_t)(pow2_at_least(Sc) + pow2_at_least(Si)) * sizeof(uint64_t));
     NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_fine: Sc+Si=%d needs %zu bytes of LDS (> 160 KiB)", Sc + Si, lds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine<0, 0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(k_sample_fine<0, 0>), lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_sample_fine: LDS attribute: %s", hipGetErrorString(e));
     }
     int64_t g = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -320,8 +319,7 @@ int nerf_sample_pdf(int64_t n, int n_bins, int Si, const float* bins, const floa
                                                   (size_t)(pow2_at_least(Sc) + pow2_at_least(Si)) * sizeof(uint64_t));
     NERF_REQUIRE(lds <= 160 * 1024, "nerf_sample_pdf: n_bins+Si=%d needs %zu bytes of LDS (> 160 KiB)", n_bins + Si, lds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_fine<0, 0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = lds_limit_once(reinterpret_cast<const void*>(k_sample_fine<0, 0>), lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_sample_pdf: LDS attribute: %s", hipGetErrorString(e));
     }
     int64_t g = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;

@@ -263,13 +263,26 @@ def test_linear_layer_kernel_against_fp64(device, n, n_in, n_out, relu, bias):
         scale = float(t.abs().max()) + 1e-30
         err_cpu, err_gpu = float((c - t).abs().max()) / scale, float((h - t).abs().max()) / scale
         assert h.shape == t.shape, name
-        # a wave adds its k-values one after the other in fp32: the error of such a sum grows like eps * sqrt(terms),
-        # where the CPU's blocked sums stay flatter
-        terms = {"y": n_in, "dx": n_out, "dw": n, "db": n}[name]
         if safe or name == "y":
-            assert err_gpu <= max(2e-6, 3 * err_cpu, 1.2e-7 * np.sqrt(terms)), (name, n, n_in, n_out, err_gpu, err_cpu)
+            assert err_gpu <= max(2e-6, 3 * err_cpu), (name, n, n_in, n_out, err_gpu, err_cpu)
         else:
             assert err_gpu <= 1e-3, (name, err_gpu)
     again = run(xd, w.to(device), None if b is None else b.to(device), torch.float32, lambda x, w, b: ops.linear(x, w, b, relu))
     for a, c in zip(got, again):
         exact(a, c, "bitwise reproducible")
+
+
+def test_relu_gradient_lets_the_gradient_of_a_nan_unit_through(device):
+    """A unit whose forward value is NaN: torch's threshold_backward zeroes the gradient where the output is <= 0, which a
+    NaN is not, so the incoming gradient passes; the library's layer-by-layer backward does the same."""
+    from nerf_amd import ops
+    x = torch.tensor([[1.0, -2.0, 0.5, 0.0, 3.0]], device=device)
+    w = torch.eye(5, device=device)
+    b = torch.tensor([0.0, 0.0, float("nan"), 0.0, 0.0], device=device)      # unit 2 is NaN in the forward pass, the others finite
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ops.linear(xr, wr, br, True).backward(torch.ones(1, 5, device=device))
+    xt, wt, bt = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    torch.relu(torch.nn.functional.linear(xt, wt, bt)).backward(torch.ones(1, 5, device=device))
+    for got, want, what in ((xr.grad, xt.grad, "dx"), (wr.grad, wt.grad, "dw"), (br.grad, bt.grad, "db")):
+        exact(got, want, what)
+    assert float(xr.grad[0, 2]) == 1.0 and float(xr.grad[0, 1]) == 0.0 and float(xr.grad[0, 3]) == 0.0
