@@ -71,14 +71,15 @@ constexpr int x2_stores_since_open(int I, int NKS) {
 
 // One layer: NOUT row tiles (16 features each) x NKS k-steps (32 input features each) x NCT2 column tiles.
 // in_frag<CT, ks, S>() = piece S (0 hi, 1 lo) of the input fragment of column tile CT, k-step ks; Y[S][CT][..] receives
-// the pieces of the output (STORE); mx[CT] the largest magnitude this lane has produced for column tile CT.
+// the pieces of the output (STORE); mx[CT] the largest magnitude this lane has produced for column tile CT, kept as the
+// fp16 bits of the leading pieces (two running maxima per word; SIGNED = the values may be negative).
 // SAVE / MASK (training): as layer_x3 of mlp_fwd_bf16x3.hip -- the unsplit fp32 values of a finished tile are stored in
 // the blocked layout of mlp_layout.hpp, their ReLU mask bits collected in mb.
-template <int NOUT, int NKS, int NHEAD, bool STORE, bool SAVE, bool MASK, typename InFrag>
+template <int NOUT, int NKS, int NHEAD, bool STORE, bool SAVE, bool MASK, bool SIGNED, typename InFrag>
 __device__ __forceinline__ void layer_x2(Stream2& st, int lane, int g, const char*& cur, InFrag in_frag,
                                          u32x4 (&Y)[2][NCT2][8], const float* bias_lds, float lo, const float* head_lds,
                                          int head_stride, float (&head)[NCT2][3], float* (&srow)[NCT2],
-                                         uint32_t (&mb)[NCT2][4], float (&mx)[NCT2]) {
+                                         uint32_t (&mb)[NCT2][4], uint32_t (&mx)[NCT2]) {
     constexpr int NB = NOUT * NKS, DEPTH = 3, NPIECE = 4 * NCT2;
     constexpr bool BIAS_INIT = NKS >= 7;
     constexpr int PPS = (NPIECE + (NKS < 8 ? NKS : 8) - 1) / (NKS < 8 ? NKS : 8);   // epilogue values per k-step
@@ -123,7 +124,7 @@ __device__ __forceinline__ void layer_x2(Stream2& st, int lane, int g, const cha
                 split2_pair(pv, v, h, l);
                 Y[0][ct][f][w] = h;
                 Y[1][ct][f][w] = l;
-                mx[ct] = run_max(mx[ct], pv, v);
+                mx[ct] = run_max_h(mx[ct], SIGNED ? (h & 0x7fff7fffu) : h);   // (behind a ReLU the sign bits are clear already)
             }
         }
     };
@@ -199,7 +200,7 @@ k_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, c
     constexpr int NF = enc2_frags(UV);
     u32x4* ed = reinterpret_cast<u32x4*>(smem2 + RING2_BYTES + aux2_floats(UV) * 4) + wave * (2 * NF * 64) + lane;
     uint32_t* wave_flags = reinterpret_cast<uint32_t*>(smem2 + RING2_BYTES + aux2_floats(UV) * 4 + X2_WAVES * 2 * NF * 64 * 16);
-    float mx[NCT2];
+    uint32_t mx[NCT2];
     bool bad = false;
     auto park = [&](int f, const float* v, float& m) {
         u32x4 h, l;
@@ -221,8 +222,13 @@ k_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, c
     auto check = [&]() {
 #pragma unroll
         for (int ct = 0; ct < NCT2; ++ct) {
-            bad |= out_of_range(over_groups_max(mx[ct]));
-            mx[ct] = 0.0f;
+            uint32_t m = (mx[ct] & 0xffffu) > (mx[ct] >> 16) ? (mx[ct] & 0xffffu) : (mx[ct] >> 16);
+            const uint32_t m1 = (uint32_t)__shfl_xor((int)m, 16, 64);
+            m = m > m1 ? m : m1;
+            const uint32_t m2 = (uint32_t)__shfl_xor((int)m, 32, 64);
+            m = m > m2 ? m : m2;
+            bad |= out_of_range_h(m);
+            mx[ct] = 0u;
         }
     };
     int64_t p[NCT2];
@@ -282,7 +288,7 @@ k_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, c
                 }
             }
         }
-        mx[ct] = 0.0f;
+        mx[ct] = 0u;
     }
 
     Stream2 st;
@@ -347,7 +353,7 @@ k_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, c
     float* sr[NCT2];
 #define X2_LAYER(NOUT, NKS, NHEAD, STORE, MASKED, IN, OUT, BIAS, LO, HEADW, HSTRIDE, HEAD, ROW)                        \
     rows(ROW, sr);                                                                                                    \
-    layer_x2<NOUT, NKS, NHEAD, STORE, SAVE, SAVE && MASKED>(st, lane, g, cur, IN, OUT, BIAS, LO, HEADW, HSTRIDE, HEAD, sr, mb, mx)
+    layer_x2<NOUT, NKS, NHEAD, STORE, SAVE, SAVE && MASKED, !(MASKED)>(st, lane, g, cur, IN, OUT, BIAS, LO, HEADW, HSTRIDE, HEAD, sr, mb, mx)
 
     X2_LAYER(16, 2, 0, true, true, fromE, X, bias, 0.0f, hw, 0, sig, ACT_H0);                               // L0
     save_mask(0); check();

@@ -12,8 +12,8 @@
 // That holds while the leading piece is a NORMAL fp16: |x| in [2^-14, 65504].  Below, hi loses bits (absolute error
 // 2^-36 instead of relative 2^-22); above, hi is infinite.  The kernels therefore watch the largest magnitude each lane
 // sees per layer: a lane whose largest value is >= 2^15 (or infinite), or whose largest value is < 2^-11, marks its
-// 128-point tile, and marked tiles are recomputed by the bf16 three-piece kernel, whose exactness does not depend on
-// magnitude.  Values far below a lane's largest contribute below fp32 rounding of the sum whether or not their own
+// 128-point tile (a largest value of exactly 0 stands: zeros are exact), and marked tiles are recomputed by the bf16
+// three-piece kernel, whose exactness does not depend on magnitude.  Values far below a lane's largest contribute below fp32 rounding of the sum whether or not their own
 // relative precision is kept.  The same rule applied per layer to the weights at packing time marks every tile.
 #pragma once
 #include "mlp_core.hpp"
@@ -48,12 +48,17 @@ __host__ __device__ inline void split2(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((x - (float)hi) * LO_SCALE);
 }
 
-// two values -> one 32-bit word per piece (value 0 in the low half)
+// two values -> one 32-bit word per piece (value 0 in the low half).  The residual is one fused multiply-add per
+// value, fp16(v * 2^11 - hi * 2^11): both products are exact (powers of two) and so is their difference, so the result
+// equals scaling v - hi, and v_fma_mixlo / mixhi_f16 reads hi as fp16 and rounds the result to fp16 by itself: five
+// instructions per pair (one packed conversion, two multiplications, two mixed fused multiply-adds) instead of eight.
 __device__ __forceinline__ void split2_pair(float v0, float v1, uint32_t& hi, uint32_t& lo) {
     const f16x2 h = {(_Float16)v0, (_Float16)v1};
-    const f16x2 l = {(_Float16)((v0 - (float)h[0]) * LO_SCALE), (_Float16)((v1 - (float)h[1]) * LO_SCALE)};
     hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
+    const float s0 = v0 * LO_SCALE, s1 = v1 * LO_SCALE, c = -LO_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi), "v"(c), "v"(s0), "v"(s1));
 }
 
 struct Stream2 {
@@ -96,6 +101,15 @@ __device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 c) {
 __device__ __forceinline__ float run_max(float m, float v0, float v1) {
     return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
 }
-__device__ __forceinline__ bool out_of_range(float m) { return !(m < RANGE_HIGH) || m < RANGE_LOW; }
+// (an all-zero operand set is exact on any scheme: a maximum of 0 stands)
+__device__ __forceinline__ bool out_of_range(float m) { return !(m < RANGE_HIGH) || (m < RANGE_LOW && m > 0.0f); }
+// The same rule on the fp16 bits of leading pieces (non-negative fp16 values order like their bits; a NaN sorts above
+// infinity): two running maxima per 32-bit word, then one value.
+constexpr uint32_t RANGE_HIGH_H = 0x7800u, RANGE_LOW_H = 0x1000u;     // fp16 bits of 2^15 and 2^-11
+__device__ __forceinline__ uint32_t run_max_h(uint32_t m, uint32_t pair) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, pair)));
+}
+__device__ __forceinline__ bool out_of_range_h(uint32_t m) { return m >= RANGE_HIGH_H || (m < RANGE_LOW_H && m != 0u); }
 
 }  // namespace nerfx2

@@ -101,10 +101,18 @@ def test_tiles_that_leave_the_fp16_range_are_redone_by_the_three_piece_kernel(de
         else:
             assert np.isnan(fixed).all() and np.isnan(mfma32).all()
 
-    # a dead layer: every unit of layer 1 switched off by its bias, so a point's largest operand of layer 2 is 0 < 2^-11
+    # a dead layer: every unit of layer 1 switched off by its bias.  All operands of layer 2 are exactly 0, which any
+    # scheme multiplies exactly: nothing is marked.  A layer that is merely tiny (outputs of layer 1 scaled to ~1e-5 through
+    # its weights and bias... here: its bias alone, weights zero) is below 2^-11 and goes to the three-piece kernel
     sd = O.random_state_dict(81)
     sd["pts_linears.1.bias"][:] = -1e3
-    fixed, flags, alone, three, _ = run(sd)
+    fixed, flags, alone, three, mfma32 = run(sd)
+    assert flags.sum() == 0 and same(fixed, alone)
+    np.testing.assert_allclose(fixed, mfma32, rtol=0, atol=3e-6 * float(np.abs(mfma32).max()))
+    sd = O.random_state_dict(81)
+    sd["pts_linears.1.weight"][:] = 0.0
+    sd["pts_linears.1.bias"][:] = 1e-5
+    fixed, flags, alone, three, mfma32 = run(sd)
     assert flags.all() and same(fixed, three)
 
     # weights outside the range: one weight of 1e5 (layer 3), and a whole layer of tiny weights (layer 6 x 1e-6)
