@@ -179,14 +179,16 @@ def hbm_kernels(prof):
     return out
 
 
-# algorithmic FLOP per sample point of the three MLP kernels of a train step, and the matrix instruction each runs on
-# (the split-operand kernels issue six bf16 matrix instructions per fp32-accurate product)
+# algorithmic FLOP per sample point of the MLP kernels of a train step, and how many 16-bit matrix instructions each
+# issues per fp32-accurate product: the forward runs on two fp16 pieces per operand (three instructions), backward-data
+# and the weight gradients on three bf16 pieces (six)
 TRAIN_KERNEL_FLOP = {"mlp_fwd_save": 1186816, "mlp_bwd_data": 1115392, "mlp_bwd_dw": 1186816, "mlp_bwd": 2302208}
+TRAIN_KERNEL_PRODUCTS = {"mlp_fwd_save": PAIR_PRODUCTS, "mlp_bwd_data": SPLIT_PRODUCTS, "mlp_bwd_dw": SPLIT_PRODUCTS, "mlp_bwd": SPLIT_PRODUCTS}
 
 
 def train_kernel_rooflines(prof):
-    """Per MLP kernel of the train step: algorithmic TFLOP/s from HIP events around each launch, against a sixth of the
-    dense bf16 matrix peak (what six split products per fp32 product allow)."""
+    """Per MLP kernel of the train step: algorithmic TFLOP/s from HIP events around each launch, against the dense
+    16-bit matrix peak divided by the matrix instructions the kernel issues per fp32-accurate product."""
     out = {}
     for name, flop_pt in TRAIN_KERNEL_FLOP.items():
         k = [(n, s.elapsed_time(e) * 1e-3) for (nm, n, s, e) in prof if nm == name]
@@ -194,9 +196,10 @@ def train_kernel_rooflines(prof):
         if secs <= 0:
             continue
         tf = sum(n for n, _ in k) * flop_pt / secs / 1e12
+        products = TRAIN_KERNEL_PRODUCTS[name]
         out[name] = {"launches": len(k), "ms_total": round(1e3 * secs, 3), "tflops_algorithmic": round(tf, 1),
-                     "executed_bf16_tflops": round(SPLIT_PRODUCTS * tf, 1), "peak": round(PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS, 1),
-                     "frac": round(tf / (PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS), 4)}
+                     "matrix_instructions_per_product": products, "executed_16bit_tflops": round(products * tf, 1),
+                     "peak": round(PEAK_BF16_MATRIX_TFLOPS / products, 1), "frac": round(tf / (PEAK_BF16_MATRIX_TFLOPS / products), 4)}
     return out
 
 
@@ -225,7 +228,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
             del kw["ndc"]     # as upstream's create_nerf leaves it for LLFF: render() defaults to ndc=True
         pts_per_ray = 2 * kw["N_samples"] + kw["N_importance"]
         saved = [p.detach().clone() for p in params]
-        opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=graphed, fused=True)   # as create_nerf
+        opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=True, fused=True)   # as create_nerf
         stepper = None
         if graphed:
             from nerf_amd.graph_step import GraphedTrainStep
@@ -321,6 +324,12 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     res.update(held)
     for k in res["kernels"].values():   # the three kernels ran back to back under the same clock and power
         k.update(held)
+    gpu_busy = sum(s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof) / dt
+    res["gpu_busy_share_of_step"] = round(gpu_busy, 4)
+    if gpu_busy < 0.85:
+        res["note"] = ("launch-bound in this run: the kernels of a step took %.2f ms of its %.2f ms, the rest is the launching "
+                       "thread (an eager step is 40-odd launches; on a box whose host cores are contended it falls behind the "
+                       "GPU); train_graphed is the same step replayed from HIP graphs" % (1e3 * gpu_busy * dt / steps, 1e3 * dt / steps))
     if ar_events:
         ar = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
         in_place = ar_info.get("bucket_bytes", 1) == 0

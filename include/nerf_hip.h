@@ -223,6 +223,13 @@ int nerf_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* pts, const 
 int64_t nerf_mlp_packed_f16x2_bytes(int use_viewdirs);
 int64_t nerf_mlp_f16x2_tile_points(void);
 int nerf_pack_weights_f16x2(int use_viewdirs, int output_ch, const float* params, void* packed_f16x2, void* stream);
+/* The same stream as one gather through an int32 map the caller keeps (DEVICE; as nerf_gather_split3): `table` holds 512
+ * entries per pair block and then one per fp32 table value -- the index into params of the value to split (or copy), or
+ * -1 for a zero; `out` receives pairs x 2 KiB, n_aux floats and the 16 range words.  With the map taken once per model
+ * from nerf_pack_weights_f16x2 run on the vector 1/64, 2/64, 3/64, ... (exact in two fp16 pieces), the stream is rebuilt
+ * in a few microseconds after every optimiser step.  Part of the weight hand-over of NeRF.forward
+ * (run_nerf_helpers.py:109-133); upstream has no counterpart. */
+int nerf_gather_split2(const int32_t* table, const float* params, void* out, int64_t pairs, int64_t n_aux, void* stream);
 int nerf_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                        int use_viewdirs, int output_ch, const void* packed_f16x2, const void* packed_bf16x3,
                        float* out, float* act, uint32_t* tile_flags, void* stream);

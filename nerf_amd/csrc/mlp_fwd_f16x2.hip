@@ -461,6 +461,38 @@ __global__ void __launch_bounds__(256) k_pack_f16x2(int use_viewdirs, int output
     }
 }
 
+// The same stream as ONE gather through a map (nerf_gather_split2): element pair (pair block, w, w + 1) reads its two
+// sources, splits them and writes one 4-byte word per piece; then the fp32 tables; the range words as in k_pack_f16x2.
+__global__ void __launch_bounds__(256) k_gather_split2(const int32_t* __restrict__ table, const float* __restrict__ params,
+                                                       char* __restrict__ out, int64_t npairs, int64_t n_aux) {
+    const int64_t words = npairs * 256;            // two stream elements each
+    const int64_t total = words + n_aux;
+    uint32_t* range = reinterpret_cast<uint32_t*>(out + npairs * PAIR_BYTES + n_aux * 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total + 63) / 64 * 64; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t mag = 0u;
+        if (i < words) {
+            const int2 src = reinterpret_cast<const int2*>(table)[i];
+            const float x0 = src.x < 0 ? 0.0f : params[src.x], x1 = src.y < 0 ? 0.0f : params[src.y];
+            uint32_t hw, lw;
+            split2_pair(x0, x1, hw, lw);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(out + (i >> 8) * PAIR_BYTES) + (i & 255);
+            dst[0] = hw;
+            dst[256] = lw;
+            const uint32_t m0 = __float_as_uint(x0) & 0x7fffffffu, m1 = __float_as_uint(x1) & 0x7fffffffu;
+            mag = m0 > m1 ? m0 : m1;
+        } else if (i < total) {
+            const int32_t src = table[2 * words + (i - words)];
+            reinterpret_cast<float*>(out + npairs * PAIR_BYTES)[i - words] = src < 0 ? 0.0f : params[src];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {   // a wave's 64 words lie in one block, hence in one section
+            const uint32_t o = (uint32_t)__shfl_xor((int)mag, off, 64);
+            mag = o > mag ? o : mag;
+        }
+        if ((threadIdx.x & 63) == 0 && i < words && mag != 0u) atomicMax(range + x2_block_section((int)(i >> 8)), mag);
+    }
+}
+
 constexpr size_t x2_lds_bytes(int uv) {
     return RING2_BYTES + aux2_floats(uv) * sizeof(float) + X2_WAVES * 2 * enc2_frags(uv) * 64 * 16 + X2_WAVES * sizeof(uint32_t);
 }
@@ -486,6 +518,22 @@ int nerf_pack_weights_f16x2(int use_viewdirs, int output_ch, const float* params
     hipLaunchKernelGGL(k_pack_f16x2, dim3(1024), dim3(256), 0, as_stream(stream), use_viewdirs, output_ch, params,
                        reinterpret_cast<char*>(packed));
     return launched("nerf_pack_weights_f16x2");
+}
+
+int nerf_gather_split2(const int32_t* table, const float* params, void* out, int64_t pairs, int64_t n_aux, void* stream) {
+    NERF_REQUIRE(pairs >= 0 && n_aux >= 0, "nerf_gather_split2: negative count");
+    if (pairs + n_aux == 0) return 0;
+    NERF_REQUIRE(table && params && out, "nerf_gather_split2: null pointer");
+    NERF_REQUIRE(pairs % SLABP == 0 && n_aux % 4 == 0, "nerf_gather_split2: pairs=%lld must be whole slabs and n_aux=%lld a multiple of 4",
+                 (long long)pairs, (long long)n_aux);
+    NERF_REQUIRE((reinterpret_cast<uintptr_t>(table) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                 "nerf_gather_split2: table must be 8-byte and out 16-byte aligned");
+    char* range = reinterpret_cast<char*>(out) + pairs * PAIR_BYTES + n_aux * 4;
+    hipError_t e = hipMemsetAsync(range, 0, RANGE_WORDS * 4, as_stream(stream));
+    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_gather_split2: clearing the range words: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gather_split2, dim3(1024), dim3(256), 0, as_stream(stream), table, params, reinterpret_cast<char*>(out),
+                       pairs, n_aux);
+    return launched("nerf_gather_split2");
 }
 
 int nerf_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,

@@ -446,6 +446,34 @@ def pack_weights_f16x2(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -
     return out
 
 
+def x2_pack_table(use_viewdirs: bool, output_ch: int, dev):
+    """(int32 source map of the fp16-pair stream and its fp32 tables, pair blocks, fp32 table entries): the packing kernel
+    run once on the vector 1/64, 2/64, 3/64, ... -- a network has under 2^20 parameters, so every value has at most 20
+    significant bits and stays below fp16's largest: its two pieces add up to it exactly."""
+    n = mlp_n_params(use_viewdirs, output_ch)
+    assert n < (1 << 20)
+    ramp = torch.arange(1, n + 1, dtype=torch.float32, device=dev) / 64.0
+    raw = pack_weights_f16x2(ramp, use_viewdirs, output_ch)
+    tile = 2048
+    total = lib.nerf_mlp_packed_f16x2_bytes(int(use_viewdirs))
+    pairs = lib.nerf_mlp_bf16x3_triples(int(use_viewdirs))   # one pair block per weight block, as many as triples
+    n_aux = (total - 64 - pairs * tile) // 4                 # behind the pair blocks: the fp32 tables and 16 range words
+    assert pairs * tile + n_aux * 4 + 64 == total and n_aux > 0
+    halves = raw[:pairs * tile].view(torch.float16).reshape(pairs, 2, 512).double()
+    src = torch.cat([((halves[:, 0] + halves[:, 1] / 2048.0) * 64.0).reshape(-1),
+                     raw[pairs * tile: pairs * tile + n_aux * 4].view(torch.float32).double() * 64.0])
+    return (src.round().to(torch.int32) - 1).contiguous(), pairs, n_aux
+
+
+def pack_weights_f16x2_gather(flat: torch.Tensor, table: torch.Tensor, pairs: int, n_aux: int) -> torch.Tensor:
+    """The fp16-pair stream (with its fp32 tables and range words) in one gather-and-split launch."""
+    flat = _f32c(flat, "params")
+    out = torch.empty(pairs * 2048 + n_aux * 4 + 64, dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_gather_split2(table.data_ptr(), flat.data_ptr(), out.data_ptr(), pairs, n_aux, _stream()))
+    return out
+
+
 def mlp_forward_f16x2(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed: torch.Tensor, packed_x3: Optional[torch.Tensor],
                       use_viewdirs: bool, output_ch: int, pts_per_ray: int, act: Optional[torch.Tensor] = None,
                       want_flags: bool = False):
@@ -618,7 +646,7 @@ class _FusedMLP(torch.autograd.Function):
 
 
 def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_per_ray: int) -> torch.Tensor:
-    params = list(model.parameters())
+    params = model._params() if hasattr(model, "_params") else list(model.parameters())
     _no_input_grad(pts, "fused MLP: pts")
     _no_input_grad(viewdirs, "fused MLP: viewdirs")
     # decided here, where the caller's grad mode is visible: under no_grad (rendering) nothing is saved

@@ -209,8 +209,10 @@ def create_nerf(args):
         if net is not None and net.fused_arch():
             net.adopt_flat()
 
-    # (fused: the same Adam as one multi-tensor launch per step instead of seven)
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), fused=True)
+    # (fused: the same Adam as one multi-tensor launch per step instead of seven; capturable: the step counters live on
+    # the device, so a step increments them in one launch instead of 48 host-side scalar additions -- 0.5 ms of the
+    # host's 2.6 ms per 1024-ray step -- and the optimiser can be recorded into a HIP graph; same update either way)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), fused=True, capturable=True)
 
     start = 0
     basedir = args.basedir

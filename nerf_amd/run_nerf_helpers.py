@@ -144,8 +144,10 @@ class NeRF(nn.Module):
         self._packx4 = None
         self._x4_table = None
         self._x3_table = None
+        self._x2_table = None
         self._flat_vec = None
         self._flat_addrs = ()
+        self._param_list = None
         self._pack16x3 = None
         self._pack16x3b = None
         self._pack16x2 = None
@@ -183,7 +185,7 @@ class NeRF(nn.Module):
         the buffer is rebuilt from the current values.  Every packed stream is dropped when a parameter changed
         (in-place updates bump the tensors' version counters)."""
         self._check_arch()
-        params = list(self.parameters())
+        params = self._params()
         store = self._flat_vec
         if store is None or any(p.data_ptr() != a for p, a in zip(params, self._flat_addrs)):
             with torch.no_grad():
@@ -202,6 +204,18 @@ class NeRF(nn.Module):
             self._pack_key = key
             self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = self._pack16x2 = None
         return store
+
+    def _params(self):
+        """list(self.parameters()), kept: walking the module tree costs more than everything else a query does on the
+        host (dropped by _apply; a module whose layers are REPLACED afterwards must set _param_list = None itself)."""
+        if self._param_list is None:
+            self._param_list = list(self.parameters())
+        return self._param_list
+
+    def _apply(self, fn, recurse=True):
+        """`.to()`, `.cuda()`, `.float()`, ...: the parameters may be replaced, so the cached list of them is dropped."""
+        self._param_list = None
+        return super()._apply(fn, recurse)
 
     def adopt_flat(self) -> None:
         """Move the parameters into the module's flat buffer now (see _flat) instead of at the first query: call it after
@@ -246,7 +260,9 @@ class NeRF(nn.Module):
         """Stream of fp16 pairs of the no-grad query."""
         flat = self._flat()
         if self._pack16x2 is None:
-            self._pack16x2 = ops.pack_weights_f16x2(flat, self.use_viewdirs, self.output_ch)
+            if self._x2_table is None or self._x2_table[0].device != flat.device:
+                self._x2_table = ops.x2_pack_table(self.use_viewdirs, self.output_ch, flat.device)
+            self._pack16x2 = ops.pack_weights_f16x2_gather(flat, *self._x2_table)
         return self._pack16x2
 
     def _packed_bwd_bf16x3(self):
@@ -278,7 +294,7 @@ class NeRF(nn.Module):
 
     def _split_flat(self, flat: torch.Tensor):
         out, off = [], 0
-        for p in self.parameters():
+        for p in self._params():
             out.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         return out

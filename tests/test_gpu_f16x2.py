@@ -123,3 +123,20 @@ def test_tiles_that_leave_the_fp16_range_are_redone_by_the_three_piece_kernel(de
         assert flags.all() and same(fixed, three), name
         if name.endswith("6.weight"):   # (behind a weight of 1e5 the sums cancel, and any two fp32 summation orders part ways)
             np.testing.assert_allclose(fixed, mfma32, rtol=0, atol=3e-6 * float(np.abs(mfma32).max()), err_msg=name)
+
+
+@pytest.mark.parametrize("use_viewdirs,output_ch", [(True, 5), (False, 4), (False, 5)])
+def test_pair_stream_from_one_gather_equals_the_packing_kernel(device, use_viewdirs, output_ch):
+    """nerf_gather_split2 through the map taken from the packing kernel rebuilds the fp16-pair stream, its fp32 tables and
+    its range words bit for bit, on ordinary weights and on values whose pieces carry signs, zeros and fp16 overflow."""
+    from nerf_amd import ops
+    n = ops.mlp_n_params(use_viewdirs, output_ch)
+    table = ops.x2_pack_table(use_viewdirs, output_ch, device)
+    rng = np.random.Generator(np.random.PCG64(3))
+    for scale in (1.0, 1e-3, 1e5):
+        flat = T((rng.standard_normal(n) * scale).astype(np.float32)).to(device)
+        flat[::7] = 0.0
+        flat[1::11] = -flat[1::11].abs()
+        a = ops.pack_weights_f16x2_gather(flat, *table)
+        b = ops.pack_weights_f16x2(flat, use_viewdirs, output_ch)
+        assert torch.equal(a, b), scale
