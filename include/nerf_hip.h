@@ -224,12 +224,15 @@ int64_t nerf_mlp_packed_f16x2_bytes(int use_viewdirs);
 int64_t nerf_mlp_f16x2_tile_points(void);
 int nerf_pack_weights_f16x2(int use_viewdirs, int output_ch, const float* params, void* packed_f16x2, void* stream);
 /* The same stream as one gather through an int32 map the caller keeps (DEVICE; as nerf_gather_split3): `table` holds 512
- * entries per pair block and then one per fp32 table value -- the index into params of the value to split (or copy), or
- * -1 for a zero; `out` receives pairs x 2 KiB, n_aux floats and the 16 range words.  With the map taken once per model
- * from nerf_pack_weights_f16x2 run on the vector 1/64, 2/64, 3/64, ... (exact in two fp16 pieces), the stream is rebuilt
- * in a few microseconds after every optimiser step.  Part of the weight hand-over of NeRF.forward
+ * entries per pair block, then one per fp32 table value, then 512 per pair block of a second stream (pairs1 blocks; the
+ * transposed stream of nerf_mlp_bwd_data_f16x2, or 0) -- the index into params of the value to split (or copy), or
+ * -1 for a zero; `out` receives pairs x 2 KiB, n_aux floats (a multiple of 4), the 16 range words (over the first
+ * stream's weights) and pairs1 x 2 KiB.  With the map taken once per model from nerf_pack_weights_f16x2 (and
+ * nerf_pack_weights_bwd_f16x2) run on the vector 1/64, 2/64, 3/64, ... (exact in two fp16 pieces), the streams are
+ * rebuilt in a few microseconds after every optimiser step.  Part of the weight hand-over of NeRF.forward
  * (run_nerf_helpers.py:109-133); upstream has no counterpart. */
-int nerf_gather_split2(const int32_t* table, const float* params, void* out, int64_t pairs, int64_t n_aux, void* stream);
+int nerf_gather_split2(const int32_t* table, const float* params, void* out, int64_t pairs, int64_t n_aux, int64_t pairs1,
+                       void* stream);
 int nerf_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs,
                        int use_viewdirs, int output_ch, const void* packed_f16x2, const void* packed_bf16x3,
                        float* out, float* act, uint32_t* tile_flags, void* stream);
@@ -277,6 +280,27 @@ int nerf_mlp_bwd_data_bf16x3(int64_t n_pts, const float* d_out, const float* act
                              const void* packed_bf16x3, const void* packed_bwd_bf16x3, float* scratch, void* stream);
 int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdirs, int output_ch, float* scratch,
                                 float* d_params, void* stream);
+
+/* Backward-data on the fp16 matrix instruction, two pieces per operand: the first stage of the parameter-gradient
+ * pass (same d_out / act / scratch and the same dY rows as nerf_mlp_bwd_data_bf16x3; autograd of
+ * run_nerf_helpers.py:109-133), the mirror of nerf_mlp_fwd_f16x2, three matrix instructions per product.  Gradients lie
+ * far below fp16's normal range, so every point carries a power-of-two scale (the stage is linear in each point's
+ * d_out and a multiplication by 2^k is exact): the point's largest |d_out| starts at 2^8 and the scale is moved after
+ * every layer so that the largest value just produced sits at 2^8 again; what is stored is unscaled fp32.  The range
+ * rule of nerf_mlp_fwd_f16x2 then holds per point and layer, and tile_flags (DEVICE, one word per 128-point tile of the
+ * padded point range, caller-owned, need not be initialised) receives 1 where it was left (a layer that grows a
+ * point's gradient by 2^7 or shrinks its largest entry by 2^19, an infinite or NaN gradient, weights out of range).
+ * With the two three-piece streams (nerf_pack_weights_bf16x3 / nerf_pack_weights_bwd_bf16x3) the marked tiles are
+ * recomputed by the three-piece kernel in a second launch on the same stream; with both NULL only the first launch runs.
+ * packed_f16x2: the forward stream of nerf_pack_weights_f16x2 (its fp32 tables and range words are read);
+ * packed_bwd_f16x2: nerf_mlp_packed_bwd_f16x2_bytes() bytes built by nerf_pack_weights_bwd_f16x2 (W^T of the layers as
+ * pairs of 1 KiB A-operand blocks hi | lo), or the second stream of nerf_gather_split2.  The weight-gradient stage
+ * that follows is nerf_mlp_bwd_weights_bf16x3. */
+int64_t nerf_mlp_packed_bwd_f16x2_bytes(int use_viewdirs);
+int nerf_pack_weights_bwd_f16x2(int use_viewdirs, int output_ch, const float* params, void* packed_bwd_f16x2, void* stream);
+int nerf_mlp_bwd_data_f16x2(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
+                            const void* packed_f16x2, const void* packed_bwd_f16x2, const void* packed_bf16x3,
+                            const void* packed_bwd_bf16x3, float* scratch, uint32_t* tile_flags, void* stream);
 
 /* ---- nn.Linear for network shapes the fused kernels do not cover --------------------------------------------------
  * (other --netdepth / --netwidth / --multires, --i_embed -1: NeRF.forward layer by layer, run_nerf_helpers.py:109-133,

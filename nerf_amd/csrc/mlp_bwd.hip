@@ -22,7 +22,8 @@
 // stage 1 on the split-operand kernel (mlp_bwd_bf16x3.hip)
 namespace nerfx3 {
 int launch_bwd_data_x3(int64_t n_pts, int use_viewdirs, int output_ch, const float* d_out, const float* act,
-                       const void* packed_x3, const void* packed_bwd_x3, float* scratch, hipStream_t stream);
+                       const void* packed_x3, const void* packed_bwd_x3, float* scratch, const uint32_t* marked,
+                       hipStream_t stream);
 }
 
 using namespace nerfhip;
@@ -496,7 +497,7 @@ int nerf_mlp_bwd_data_bf16x3(int64_t n_pts, const float* d_out, const float* act
                              const void* packed_x3, const void* packed_bwd_x3, float* scratch, void* stream_) {
     int rc = check_bwd_x3("nerf_mlp_bwd_data_bf16x3", n_pts, d_out, act, use_viewdirs, output_ch, packed_x3, packed_bwd_x3, scratch);
     if (rc || n_pts == 0) return rc;
-    return nerfx3::launch_bwd_data_x3(n_pts, use_viewdirs, output_ch, d_out, act, packed_x3, packed_bwd_x3, scratch, as_stream(stream_));
+    return nerfx3::launch_bwd_data_x3(n_pts, use_viewdirs, output_ch, d_out, act, packed_x3, packed_bwd_x3, scratch, nullptr, as_stream(stream_));
 }
 
 int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdirs, int output_ch, float* scratch,

@@ -10,6 +10,7 @@
 #include "mlp_tile16.hpp"
 #include "mlp_bf16_layout.hpp"
 #include "mlp_x3.hpp"
+#include "mlp_bwd16_layout.hpp"
 
 using namespace nerfhip;
 using namespace nerflayout;
@@ -17,33 +18,11 @@ using namespace nerfmlp;
 using namespace nerftile16;
 using namespace nerfbf16;
 using namespace nerfx3;
+using namespace nerfbwd16;
 
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// ---- transposed stream ---------------------------------------------------------------------------
-// Sections (triples; row tile by row tile, a tile's k-steps consecutively; every section is a whole number of slabs):
-//   view branch: Wviews[:, :256]^T 64 (16 row tiles x 4 k-steps) | Wfeature^T 128 (16 x 8) |
-//   then W7^T, W6^T, W5[:, 63:]^T, W4^T, ... W1^T, 128 each.
-__host__ __device__ inline int x3b_stream_triples(int use_viewdirs) { return use_viewdirs ? 64 + 8 * 128 : 7 * 128; }
-
-// flat-parameter index of stream element (triple, lane, j): M[16 to + r][32 ks + kslot(g, j)] with M = W^T
-__host__ __device__ inline int64_t x3b_stream_source(int use_viewdirs, int output_ch, int t, int lane, int j) {
-    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
-    const int r16 = lane & 15, g = lane >> 4;
-    if (use_viewdirs) {
-        if (t < 64) return po.views_w + (int64_t)(32 * (t & 3) + kslot_feature(g, j)) * po.views_in + 16 * (t >> 2) + r16;
-        t -= 64;
-        if (t < 128) return po.feat_w + (int64_t)(32 * (t & 7) + kslot_feature(g, j)) * W + 16 * (t >> 3) + r16;
-        t -= 128;
-    }
-    const int layer = 7 - t / 128;   // 7, 6, ..., 1: the section turns dY of this layer into dL/d(output of layer - 1)
-    t %= 128;
-    const int64_t row = 32 * (t & 7) + kslot_feature(g, j), col = 16 * (t >> 3) + r16;
-    if (layer == 5) return po.pts_w[5] + row * (W + IN_PTS) + IN_PTS + col;
-    return po.pts_w[layer] + row * W + col;
-}
 
 // One backward-data layer: out = keep(start + M in), M = the section's W^T.  keep (MASK) zeroes the entries whose forward
 // activation was not positive: bit 8 (t % 4) + 4 (g >> 1) + r of dword t / 4 of mw[ct] stands for value r of tile t
@@ -125,7 +104,9 @@ __device__ __forceinline__ void layer_x3b(Stream3& st, int lane, int g, const ch
 template <bool VIEWDIRS>
 __global__ void __launch_bounds__(X3_THREADS, 1)
 k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_out, const float* __restrict__ act,
-                      const char* __restrict__ packed_x3, const char* __restrict__ packed_bwd, float* __restrict__ scr) {
+                      const char* __restrict__ packed_x3, const char* __restrict__ packed_bwd, float* __restrict__ scr,
+                      const uint32_t* __restrict__ marked) {
+    if (marked != nullptr && marked[blockIdx.x] == 0u) return;   // (second launch behind the two-piece kernel: marked tiles only)
     extern __shared__ __attribute__((aligned(16))) char smem3b[];
     char* ring = smem3b;
     float* aux = reinterpret_cast<float*>(smem3b + RING3_BYTES);
@@ -156,7 +137,7 @@ k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_
     st.mine = ring + wave * WAVE_BLOCKS3 * 1024;
     st.g = packed_bwd + wave * WAVE_BLOCKS3 * 1024 + lane * 16;
     st.next = 0;
-    st.nslabs = x3b_stream_triples(UV) / SLABT;
+    st.nslabs = bwd16_stream_blocks(UV) / SLABT;
     __syncthreads();
     st.fetch(0);
     st.fetch(1);
@@ -282,13 +263,13 @@ k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_
 // flat parameters -> transposed stream of triples
 __global__ void __launch_bounds__(256) k_pack_x3b(int use_viewdirs, int output_ch, const float* __restrict__ params,
                                                   char* __restrict__ out) {
-    const int64_t elems = (int64_t)x3b_stream_triples(use_viewdirs) * 512;   // one per (triple, lane, slot)
+    const int64_t elems = (int64_t)bwd16_stream_blocks(use_viewdirs) * 512;   // one per (triple, lane, slot)
     unsigned short* s16 = reinterpret_cast<unsigned short*>(out);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i >> 9;
         const int w = (int)(i & 511);
         __bf16 h, m, l;
-        split3(params[x3b_stream_source(use_viewdirs, output_ch, (int)t, w >> 3, w & 7)], h, m, l);
+        split3(params[bwd16_stream_source(use_viewdirs, output_ch, (int)t, w >> 3, w & 7)], h, m, l);
         unsigned short* dst = s16 + t * (TRIPLE_BYTES / 2) + w;
         dst[0] = __builtin_bit_cast(unsigned short, h);
         dst[512] = __builtin_bit_cast(unsigned short, m);
@@ -302,14 +283,16 @@ constexpr size_t X3B_LDS_BYTES = RING3_BYTES + AUX16_FLOATS * sizeof(float);
 
 namespace nerfx3 {
 
+// marked: nullptr = every 128-point tile; else one word per tile, and only the tiles whose word is not 0 are computed
 int launch_bwd_data_x3(int64_t n_pts, int use_viewdirs, int output_ch, const float* d_out, const float* act,
-                       const void* packed_x3, const void* packed_bwd_x3, float* scratch, hipStream_t stream) {
+                       const void* packed_x3, const void* packed_bwd_x3, float* scratch, const uint32_t* marked,
+                       hipStream_t stream) {
     const int64_t blocks = padded_points(n_pts) / TILE_PTS;
     auto go = [&](auto kernel, int och) -> int {
         hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), X3B_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), X3B_LDS_BYTES, stream, n_pts, och, d_out, act,
-                           reinterpret_cast<const char*>(packed_x3), reinterpret_cast<const char*>(packed_bwd_x3), scratch);
+                           reinterpret_cast<const char*>(packed_x3), reinterpret_cast<const char*>(packed_bwd_x3), scratch, marked);
         return launched("nerf_mlp_bwd_bf16x3 (data)");
     };
     return use_viewdirs ? go(k_mlp_bwd_data_bf16x3<true>, 4) : go(k_mlp_bwd_data_bf16x3<false>, output_ch);
@@ -319,7 +302,7 @@ int launch_bwd_data_x3(int64_t n_pts, int use_viewdirs, int output_ch, const flo
 
 extern "C" {
 
-int64_t nerf_mlp_packed_bwd_bf16x3_bytes(int use_viewdirs) { return (int64_t)x3b_stream_triples(use_viewdirs) * TRIPLE_BYTES; }
+int64_t nerf_mlp_packed_bwd_bf16x3_bytes(int use_viewdirs) { return (int64_t)bwd16_stream_blocks(use_viewdirs) * TRIPLE_BYTES; }
 
 int nerf_pack_weights_bwd_bf16x3(int use_viewdirs, int output_ch, const float* params, void* packed, void* stream) {
     NERF_REQUIRE(params && packed, "nerf_pack_weights_bwd_bf16x3: null pointer");

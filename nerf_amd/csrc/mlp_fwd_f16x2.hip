@@ -28,46 +28,9 @@ using namespace nerfx2;
 
 namespace {
 
-__host__ __device__ inline int x2_stream_slabs(int use_viewdirs) { return bf16_stream_blocks(use_viewdirs) / SLABP; }
-__host__ __device__ inline int64_t x2_packed_bytes(int use_viewdirs) {
-    return (int64_t)x2_stream_slabs(use_viewdirs) * SLAB2_BYTES + (int64_t)AUX16_FLOATS * 4 + RANGE_WORDS * 4;
-}
-// section of the stream (mlp_bf16_layout.hpp) a block belongs to: 0..7 pts layers, 8 feature, 9 views
-__host__ __device__ inline int x2_block_section(int blk) {
-    if (blk < 32) return 0;
-    blk -= 32;
-    for (int l = 1; l < 8; ++l) {
-        const int n = (l == 5) ? 160 : 128;
-        if (blk < n) return l;
-        blk -= n;
-    }
-    return blk < 128 ? 8 : 9;
-}
-__host__ __device__ constexpr int x2_sections(int use_viewdirs) { return use_viewdirs ? 10 : 8; }
-
 // LDS behind the ring: the fp32 tables, then the split encodings (fragments per piece and wave), then one flag per wave
 __host__ __device__ constexpr int aux2_floats(int use_viewdirs) { return use_viewdirs ? AUX16_HEAD + 648 : AUX16_FLOATS; }
 __host__ __device__ constexpr int enc2_frags(int use_viewdirs) { return (use_viewdirs ? 3 : 2) * NCT2; }
-
-// Stores of finished tiles that a layer loop of NKS k-steps per tile issues during the SLABP blocks before block I (the
-// epilogue of tile t - 1 runs value by value behind the k-steps of tile t, three blocks behind the fragment reads, and
-// writes 16 bytes per column tile when a tile's fourth value is done).  For Stream2::advance<STORES>.
-constexpr int x2_stores_since_open(int I, int NKS) {
-    constexpr int DEPTH = 3, NPIECE = 4 * NCT2;
-    const int div = NKS < 8 ? NKS : 8;
-    const int pps = (NPIECE + div - 1) / div;
-    int n = 0;
-    for (int J = I - SLABP; J < I; ++J) {
-        if (J < DEPTH) continue;
-        const int b = J - DEPTH, to = b / NKS, ks = b % NKS;
-        if (to == 0) continue;
-        for (int q = 0; q < pps; ++q) {
-            const int k = ks * pps + q;
-            if (k < NPIECE && (k & 3) == 3) ++n;
-        }
-    }
-    return n;
-}
 
 // One layer: NOUT row tiles (16 features each) x NKS k-steps (32 input features each) x NCT2 column tiles.
 // in_frag<CT, ks, S>() = piece S (0 hi, 1 lo) of the input fragment of column tile CT, k-step ks; Y[S][CT][..] receives
@@ -485,30 +448,38 @@ __global__ void __launch_bounds__(256) k_pack_f16x2(int use_viewdirs, int output
 }
 
 // The same stream as ONE gather through a map (nerf_gather_split2): element pair (pair block, w, w + 1) reads its two
-// sources, splits them and writes one 4-byte word per piece; then the fp32 tables; the range words as in k_pack_f16x2.
+// sources, splits them and writes one 4-byte word per piece; then the fp32 tables; the range words as in k_pack_f16x2;
+// behind them a second stream of pair blocks (the transposed one of mlp_bwd_f16x2.hip), whose elements are the same
+// weights again and do not count for the range words.
 __global__ void __launch_bounds__(256) k_gather_split2(const int32_t* __restrict__ table, const float* __restrict__ params,
-                                                       char* __restrict__ out, int64_t npairs, int64_t n_aux) {
+                                                       char* __restrict__ out, int64_t npairs, int64_t n_aux, int64_t npairs1) {
     const int64_t words = npairs * 256;            // two stream elements each
-    const int64_t total = words + n_aux;
+    const int64_t first = words + n_aux, total = first + npairs1 * 256;
     uint32_t* range = reinterpret_cast<uint32_t*>(out + npairs * PAIR_BYTES + n_aux * 4);
+    char* out1 = out + npairs * PAIR_BYTES + n_aux * 4 + RANGE_WORDS * 4;
     __shared__ uint32_t smax[RANGE_WORDS];
     BlockRange br{smax};
     br.begin();
+    auto pair = [&](int64_t at, uint32_t* dst) -> uint32_t {   // table entries 2 at, 2 at + 1 -> one word per piece
+        const int2 src = reinterpret_cast<const int2*>(table)[at];
+        const float x0 = src.x < 0 ? 0.0f : params[src.x], x1 = src.y < 0 ? 0.0f : params[src.y];
+        uint32_t hw, lw;
+        split2_pair(x0, x1, hw, lw);
+        dst[0] = hw;
+        dst[256] = lw;
+        const uint32_t m0 = __float_as_uint(x0) & 0x7fffffffu, m1 = __float_as_uint(x1) & 0x7fffffffu;
+        return m0 > m1 ? m0 : m1;
+    };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total + 255) / 256 * 256; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t mag = 0u;
         if (i < words) {
-            const int2 src = reinterpret_cast<const int2*>(table)[i];
-            const float x0 = src.x < 0 ? 0.0f : params[src.x], x1 = src.y < 0 ? 0.0f : params[src.y];
-            uint32_t hw, lw;
-            split2_pair(x0, x1, hw, lw);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(out + (i >> 8) * PAIR_BYTES) + (i & 255);
-            dst[0] = hw;
-            dst[256] = lw;
-            const uint32_t m0 = __float_as_uint(x0) & 0x7fffffffu, m1 = __float_as_uint(x1) & 0x7fffffffu;
-            mag = m0 > m1 ? m0 : m1;
-        } else if (i < total) {
+            mag = pair(i, reinterpret_cast<uint32_t*>(out + (i >> 8) * PAIR_BYTES) + (i & 255));
+        } else if (i < first) {
             const int32_t src = table[2 * words + (i - words)];
             reinterpret_cast<float*>(out + npairs * PAIR_BYTES)[i - words] = src < 0 ? 0.0f : params[src];
+        } else if (i < total) {
+            const int64_t j = i - first;           // (the table's second part starts n_aux entries later: n_aux is even)
+            pair(words + n_aux / 2 + j, reinterpret_cast<uint32_t*>(out1 + (j >> 8) * PAIR_BYTES) + (j & 255));
         }
         br.add(mag, i < words ? x2_block_section((int)(i >> 8)) : 0);   // a wave's 64 words lie in one block, hence in one section
     }
@@ -542,19 +513,21 @@ int nerf_pack_weights_f16x2(int use_viewdirs, int output_ch, const float* params
     return launched("nerf_pack_weights_f16x2");
 }
 
-int nerf_gather_split2(const int32_t* table, const float* params, void* out, int64_t pairs, int64_t n_aux, void* stream) {
-    NERF_REQUIRE(pairs >= 0 && n_aux >= 0, "nerf_gather_split2: negative count");
-    if (pairs + n_aux == 0) return 0;
+int nerf_gather_split2(const int32_t* table, const float* params, void* out, int64_t pairs, int64_t n_aux, int64_t pairs1,
+                       void* stream) {
+    NERF_REQUIRE(pairs >= 0 && n_aux >= 0 && pairs1 >= 0, "nerf_gather_split2: negative count");
+    if (pairs + n_aux + pairs1 == 0) return 0;
     NERF_REQUIRE(table && params && out, "nerf_gather_split2: null pointer");
-    NERF_REQUIRE(pairs % SLABP == 0 && n_aux % 4 == 0, "nerf_gather_split2: pairs=%lld must be whole slabs and n_aux=%lld a multiple of 4",
-                 (long long)pairs, (long long)n_aux);
+    NERF_REQUIRE(pairs % SLABP == 0 && pairs1 % SLABP == 0 && n_aux % 4 == 0,
+                 "nerf_gather_split2: pairs=%lld and pairs1=%lld must be whole slabs and n_aux=%lld a multiple of 4",
+                 (long long)pairs, (long long)pairs1, (long long)n_aux);
     NERF_REQUIRE((reinterpret_cast<uintptr_t>(table) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
                  "nerf_gather_split2: table must be 8-byte and out 16-byte aligned");
     char* range = reinterpret_cast<char*>(out) + pairs * PAIR_BYTES + n_aux * 4;
     hipError_t e = hipMemsetAsync(range, 0, RANGE_WORDS * 4, as_stream(stream));
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_gather_split2: clearing the range words: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k_gather_split2, dim3(256), dim3(256), 0, as_stream(stream), table, params, reinterpret_cast<char*>(out),
-                       pairs, n_aux);
+                       pairs, n_aux, pairs1);
     return launched("nerf_gather_split2");
 }
 

@@ -17,9 +17,11 @@
 // relative precision is kept.  The same rule applied per layer to the weights at packing time marks every tile.
 #pragma once
 #include "mlp_core.hpp"
+#include "mlp_bf16_layout.hpp"
 
 namespace nerfx2 {
 using namespace nerfmlp;
+using namespace nerfbf16;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -111,5 +113,47 @@ __device__ __forceinline__ uint32_t run_max_h(uint32_t m, uint32_t pair) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, pair)));
 }
 __device__ __forceinline__ bool out_of_range_h(uint32_t m) { return m >= RANGE_HIGH_H || (m < RANGE_LOW_H && m != 0u); }
+
+// ---- the packed forward stream: pair blocks in the order of mlp_bf16_layout.hpp, then the fp32 tables (AUX16_FLOATS),
+// then RANGE_WORDS words: the largest |weight| of every section
+__host__ __device__ inline int x2_stream_slabs(int use_viewdirs) { return bf16_stream_blocks(use_viewdirs) / SLABP; }
+__host__ __device__ inline int64_t x2_packed_bytes(int use_viewdirs) {
+    return (int64_t)x2_stream_slabs(use_viewdirs) * SLAB2_BYTES + (int64_t)AUX16_FLOATS * 4 + RANGE_WORDS * 4;
+}
+// section of the stream a block belongs to: 0..7 pts layers, 8 feature, 9 views
+__host__ __device__ inline int x2_block_section(int blk) {
+    if (blk < 32) return 0;
+    blk -= 32;
+    for (int l = 1; l < 8; ++l) {
+        const int n = (l == 5) ? 160 : 128;
+        if (blk < n) return l;
+        blk -= n;
+    }
+    return blk < 128 ? 8 : 9;
+}
+__host__ __device__ constexpr int x2_sections(int use_viewdirs) { return use_viewdirs ? 10 : 8; }
+
+// Stores of finished tiles that a layer loop of NKS k-steps per tile issues during the SLABP blocks before block I (the
+// epilogue of tile t - 1 runs value by value behind the k-steps of tile t, three blocks behind the fragment reads, and
+// writes 16 bytes per column tile when a tile's fourth value is done).  For Stream2::advance<STORES>.
+constexpr int x2_stores_since_open(int I, int NKS) {
+    constexpr int DEPTH = 3, NPIECE = 4 * NCT2;
+    const int div = NKS < 8 ? NKS : 8;
+    const int pps = (NPIECE + div - 1) / div;
+    int n = 0;
+    for (int J = I - SLABP; J < I; ++J) {
+        if (J < DEPTH) continue;
+        const int b = J - DEPTH, to = b / NKS, ks = b % NKS;
+        if (to == 0) continue;
+        for (int q = 0; q < pps; ++q) {
+            const int k = ks * pps + q;
+            if (k < NPIECE && (k & 3) == 3) ++n;
+        }
+    }
+    return n;
+}
+
+// 2^k as a float, -126 <= k <= 127
+__device__ __forceinline__ float pow2i(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
 
 }  // namespace nerfx2

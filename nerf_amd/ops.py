@@ -446,32 +446,50 @@ def pack_weights_f16x2(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -
     return out
 
 
+def pack_weights_bwd_f16x2(flat: torch.Tensor, use_viewdirs: bool, output_ch: int) -> torch.Tensor:
+    flat = _f32c(flat, "params")
+    assert flat.numel() == mlp_n_params(use_viewdirs, output_ch)
+    out = torch.empty(lib.nerf_mlp_packed_bwd_f16x2_bytes(int(use_viewdirs)), dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_pack_weights_bwd_f16x2(int(use_viewdirs), output_ch, flat.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
 def x2_pack_table(use_viewdirs: bool, output_ch: int, dev):
-    """(int32 source map of the fp16-pair stream and its fp32 tables, pair blocks, fp32 table entries): the packing kernel
-    run once on the vector 1/64, 2/64, 3/64, ... -- a network has under 2^20 parameters, so every value has at most 20
-    significant bits and stays below fp16's largest: its two pieces add up to it exactly."""
+    """(int32 source map of the fp16-pair stream, its fp32 tables and the transposed fp16-pair stream; pair blocks of the
+    first; fp32 table entries; pair blocks of the second): the packing kernels run once on the vector 1/64, 2/64, 3/64,
+    ... -- a network has under 2^20 parameters, so every value has at most 20 significant bits and stays below fp16's
+    largest: its two pieces add up to it exactly."""
     n = mlp_n_params(use_viewdirs, output_ch)
     assert n < (1 << 20)
     ramp = torch.arange(1, n + 1, dtype=torch.float32, device=dev) / 64.0
     raw = pack_weights_f16x2(ramp, use_viewdirs, output_ch)
+    raw_b = pack_weights_bwd_f16x2(ramp, use_viewdirs, output_ch)
     tile = 2048
     total = lib.nerf_mlp_packed_f16x2_bytes(int(use_viewdirs))
     pairs = lib.nerf_mlp_bf16x3_triples(int(use_viewdirs))   # one pair block per weight block, as many as triples
     n_aux = (total - 64 - pairs * tile) // 4                 # behind the pair blocks: the fp32 tables and 16 range words
-    assert pairs * tile + n_aux * 4 + 64 == total and n_aux > 0
-    halves = raw[:pairs * tile].view(torch.float16).reshape(pairs, 2, 512).double()
-    src = torch.cat([((halves[:, 0] + halves[:, 1] / 2048.0) * 64.0).reshape(-1),
-                     raw[pairs * tile: pairs * tile + n_aux * 4].view(torch.float32).double() * 64.0])
-    return (src.round().to(torch.int32) - 1).contiguous(), pairs, n_aux
+    assert pairs * tile + n_aux * 4 + 64 == total and n_aux > 0 and n_aux % 4 == 0 and raw_b.numel() % tile == 0
+    pairs1 = raw_b.numel() // tile
+
+    def sources(blocks, count):
+        halves = blocks.view(torch.float16).reshape(count, 2, 512).double()
+        return ((halves[:, 0] + halves[:, 1] / 2048.0) * 64.0).reshape(-1)
+    src = torch.cat([sources(raw[:pairs * tile], pairs),
+                     raw[pairs * tile: pairs * tile + n_aux * 4].view(torch.float32).double() * 64.0,
+                     sources(raw_b, pairs1)])
+    return (src.round().to(torch.int32) - 1).contiguous(), pairs, n_aux, pairs1
 
 
-def pack_weights_f16x2_gather(flat: torch.Tensor, table: torch.Tensor, pairs: int, n_aux: int) -> torch.Tensor:
-    """The fp16-pair stream (with its fp32 tables and range words) in one gather-and-split launch."""
+def pack_weights_f16x2_gather(flat: torch.Tensor, table: torch.Tensor, pairs: int, n_aux: int, pairs1: int = 0):
+    """-> (the fp16-pair stream with its fp32 tables and range words, the transposed fp16-pair stream or None when
+    pairs1 = 0) in one gather-and-split launch."""
     flat = _f32c(flat, "params")
-    out = torch.empty(pairs * 2048 + n_aux * 4 + 64, dtype=torch.uint8, device=flat.device)
+    n0 = pairs * 2048 + n_aux * 4 + 64
+    out = torch.empty(n0 + pairs1 * 2048, dtype=torch.uint8, device=flat.device)
     with torch.cuda.device(flat.device):
-        check(lib.nerf_gather_split2(table.data_ptr(), flat.data_ptr(), out.data_ptr(), pairs, n_aux, _stream()))
-    return out
+        check(lib.nerf_gather_split2(table.data_ptr(), flat.data_ptr(), out.data_ptr(), pairs, n_aux, pairs1, _stream()))
+    return out[:n0], (out[n0:] if pairs1 else None)
 
 
 def mlp_forward_f16x2(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packed: torch.Tensor, packed_x3: Optional[torch.Tensor],
@@ -597,9 +615,32 @@ def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tens
     return d_flat
 
 
+def mlp_backward_f16x2(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x2: torch.Tensor,
+                       packed_bwd_x2: torch.Tensor, packed_x3: Optional[torch.Tensor], packed_bwd_x3: Optional[torch.Tensor],
+                       use_viewdirs: bool, output_ch: int, want_flags: bool = False):
+    """Parameter gradients with backward-data on the two-piece fp16 kernel (tiles that leave its range are redone by the
+    three-piece kernel; both three-piece streams None = leave them, for tests), then the weight-gradient stage."""
+    d_out = _f32c(d_out, "d_out")
+    n_pts = d_out.shape[0]
+    scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
+    tile = lib.nerf_mlp_f16x2_tile_points()
+    flags = torch.empty(((n_pts + tile - 1) // tile,), dtype=torch.int32, device=d_out.device)
+    d_flat = torch.empty_like(flat)
+    with torch.cuda.device(d_out.device):
+        with _timed("mlp_bwd_data", n_pts):
+            check(lib.nerf_mlp_bwd_data_f16x2(n_pts, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
+                                              packed_x2.data_ptr(), packed_bwd_x2.data_ptr(), _ptr(packed_x3), _ptr(packed_bwd_x3),
+                                              scratch.data_ptr(), flags.data_ptr(), _stream()))
+        with _timed("mlp_bwd_dw", n_pts):
+            check(lib.nerf_mlp_bwd_weights_bf16x3(n_pts, act.data_ptr(), int(use_viewdirs), output_ch, scratch.data_ptr(),
+                                                  d_flat.data_ptr(), _stream()))
+    return (d_flat, flags) if want_flags else d_flat
+
+
 def train_kernels(model) -> str:
     """Which kernels a training step of `model` runs: 'mfma32' (forward, backward-data and weight gradients on the fp32
-    matrix instruction) for mlp_dtype 'f32_mfma', else 'bf16x3' (all three on the split-operand scheme)."""
+    matrix instruction) for mlp_dtype 'f32_mfma', else 'bf16x3' (all three on split operands: forward and backward-data
+    on two fp16 pieces with the three-piece fall-back, unless mlp_dtype is 'bf16x3'; weight gradients on three bf16 pieces)."""
     return "mfma32" if getattr(model, "mlp_dtype", "f32") == "f32_mfma" else "bf16x3"
 
 
@@ -609,14 +650,15 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, viewdirs, model, pts_per_ray, need_grad, *params):
         kind = train_kernels(model)
+        two_piece = kind == "bf16x3" and pts_per_ray > 0 and getattr(model, "mlp_dtype", "f32") != "bf16x3"
         flat = model._flat()
         n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
         if pts_per_ray == 0:      # pre-encoded rows (NeRF.forward(x)); every backward reads what this forward saves
             out = mlp_forward_encoded(pts, model._packed(), model.use_viewdirs, model.output_ch, act)
-        elif kind == "bf16x3" and getattr(model, "mlp_dtype", "f32") != "bf16x3":
+        elif two_piece:
             # the two-piece fp16 kernel, saving activations; marked tiles are redone (and re-saved) by the three-piece kernel
-            out = mlp_forward_f16x2(pts, viewdirs, model._packed_f16x2(), model._packed_bf16x3(with_bwd=need_grad),
+            out = mlp_forward_f16x2(pts, viewdirs, model._packed_f16x2(with_bwd=need_grad), model._packed_bf16x3(with_bwd=need_grad),
                                     model.use_viewdirs, model.output_ch, pts_per_ray, act)
         elif kind == "bf16x3":
             out = mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(with_bwd=need_grad), model.use_viewdirs, model.output_ch,
@@ -628,16 +670,22 @@ class _FusedMLP(torch.autograd.Function):
                 fwd, bwd = model._packed_bf16x3(), model._packed_bwd_bf16x3()
             else:
                 fwd, bwd = model._packed_x4(), model._packed_bwd_x4()
-            ctx.save_for_backward(act, fwd, bwd, flat)
-            ctx.kind = kind
+            if two_piece:
+                ctx.save_for_backward(act, fwd, bwd, flat, model._packed_f16x2(with_bwd=True), model._packed_bwd_f16x2())
+            else:
+                ctx.save_for_backward(act, fwd, bwd, flat)
+            ctx.kind = "f16x2" if two_piece else kind
             ctx.model = model
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        act, fwd, bwd, flat = ctx.saved_tensors
+        act, fwd, bwd, flat = ctx.saved_tensors[:4]
         model = ctx.model
-        if ctx.kind == "bf16x3":
+        if ctx.kind == "f16x2":
+            x2f, x2b = ctx.saved_tensors[4:]
+            d_flat = mlp_backward_f16x2(d_out, act, flat, x2f, x2b, fwd, bwd, model.use_viewdirs, model.output_ch)
+        elif ctx.kind == "bf16x3":
             d_flat = mlp_backward_bf16x3(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
         else:
             d_flat = mlp_backward_x4(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)

@@ -151,12 +151,14 @@ class NeRF(nn.Module):
         self._pack16x3 = None
         self._pack16x3b = None
         self._pack16x2 = None
+        self._pack16x2b = None
         # Which kernels evaluate the network:
         #   'f32' (default)  fp32 accuracy on the 16-bit matrix instructions.  No-grad queries (rendering): two fp16 pieces
         #                    per operand, three piece products per product, fp32 sums; tiles of 128 points whose operands
-        #                    leave fp16's normal range are redone on the three-piece kernel.  Training (forward,
-        #                    backward-data, weight gradients): operands split exactly into three bf16 pieces, six piece
-        #                    products per product, fp32 sums.  Either measures the error of the fp32 instruction against fp64
+        #                    leave fp16's normal range are redone on the three-piece kernel.  Training: the same two-piece
+        #                    kernel for the forward and its mirror for backward-data (every point's gradient carries a
+        #                    power-of-two scale), weight gradients with operands split exactly into three bf16 pieces, six
+        #                    piece products per product, fp32 sums.  All measure the error of the fp32 instruction against fp64
         #   'bf16x3'         the three-piece kernels everywhere, rendering included
         #   'f32_mfma'       the fp32 matrix instruction, rendering and all of training
         #   'bf16'           no-grad queries only, reduced precision: bf16 operands, fp32 sums, raw outputs within ~1e-2
@@ -202,7 +204,7 @@ class NeRF(nn.Module):
         key = (_OPT_STEPS[0],) + tuple(p._version for p in params)
         if self._pack_key != key:
             self._pack_key = key
-            self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = self._pack16x2 = None
+            self._pack = self._pack16 = self._packx4 = self._pack16x3 = self._pack16x3b = self._pack16x2 = self._pack16x2b = None
         return store
 
     def _params(self):
@@ -256,14 +258,20 @@ class NeRF(nn.Module):
                 self._pack16x3 = ops.pack_weights_bf16x3(flat, self.use_viewdirs, self.output_ch)
         return self._pack16x3
 
-    def _packed_f16x2(self):
-        """Stream of fp16 pairs of the no-grad query."""
+    def _packed_f16x2(self, with_bwd: bool = False):
+        """Stream of fp16 pairs of the default query.  with_bwd (a training step): the transposed stream of the
+        backward-data kernel comes out of the same gather-and-split launch."""
         flat = self._flat()
-        if self._pack16x2 is None:
+        if self._pack16x2 is None or (with_bwd and self._pack16x2b is None):
             if self._x2_table is None or self._x2_table[0].device != flat.device:
                 self._x2_table = ops.x2_pack_table(self.use_viewdirs, self.output_ch, flat.device)
-            self._pack16x2 = ops.pack_weights_f16x2_gather(flat, *self._x2_table)
+            table, pairs, n_aux, pairs1 = self._x2_table
+            self._pack16x2, self._pack16x2b = ops.pack_weights_f16x2_gather(flat, table, pairs, n_aux, pairs1 if with_bwd else 0)
         return self._pack16x2
+
+    def _packed_bwd_f16x2(self):
+        self._packed_f16x2(with_bwd=True)
+        return self._pack16x2b
 
     def _packed_bwd_bf16x3(self):
         self._flat()

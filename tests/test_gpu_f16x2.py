@@ -127,8 +127,9 @@ def test_tiles_that_leave_the_fp16_range_are_redone_by_the_three_piece_kernel(de
 
 @pytest.mark.parametrize("use_viewdirs,output_ch", [(True, 5), (False, 4), (False, 5)])
 def test_pair_stream_from_one_gather_equals_the_packing_kernel(device, use_viewdirs, output_ch):
-    """nerf_gather_split2 through the map taken from the packing kernel rebuilds the fp16-pair stream, its fp32 tables and
-    its range words bit for bit, on ordinary weights and on values whose pieces carry signs, zeros and fp16 overflow."""
+    """nerf_gather_split2 through the map taken from the packing kernels rebuilds the fp16-pair stream, its fp32 tables,
+    its range words and the transposed fp16-pair stream bit for bit, on ordinary weights and on values whose pieces carry
+    signs, zeros and fp16 overflow; without the second stream the first comes out the same."""
     from nerf_amd import ops
     n = ops.mlp_n_params(use_viewdirs, output_ch)
     table = ops.x2_pack_table(use_viewdirs, output_ch, device)
@@ -137,6 +138,9 @@ def test_pair_stream_from_one_gather_equals_the_packing_kernel(device, use_viewd
         flat = T((rng.standard_normal(n) * scale).astype(np.float32)).to(device)
         flat[::7] = 0.0
         flat[1::11] = -flat[1::11].abs()
-        a = ops.pack_weights_f16x2_gather(flat, *table)
+        a, at = ops.pack_weights_f16x2_gather(flat, *table)
         b = ops.pack_weights_f16x2(flat, use_viewdirs, output_ch)
         assert torch.equal(a, b), scale
+        assert torch.equal(at, ops.pack_weights_bwd_f16x2(flat, use_viewdirs, output_ch)), scale
+        a0, none = ops.pack_weights_f16x2_gather(flat, *table[:3])
+        assert none is None and torch.equal(a0, b), scale

@@ -1,0 +1,151 @@
+"""Backward-data on two fp16 pieces per operand (the default training path's first gradient stage): agreement with the
+three-piece kernel and with fp64, the per-point power-of-two scales, and the range rule with its fall-back."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from test_gpu_parity import T, _model, _peaky
+from test_gpu_f16x2 import _inputs
+
+pytestmark = pytest.mark.gpu
+
+
+class _Case:
+    """One network, one batch of points, its saved activations; the parameter gradients for an upstream gradient G on
+    the two-piece stage (with and without the fall-back) and on the three-piece stage, all behind the SAME
+    weight-gradient stage, so every difference comes from the dY rows."""
+
+    def __init__(self, device, sd, n=48, s=16, seed=5):
+        from nerf_amd import ops
+        self.ops, self.n, self.s = ops, n, s
+        rng = np.random.Generator(np.random.PCG64(seed))
+        pts, vd = _inputs(rng, n, s, span=2.0)
+        self.pts, self.vd = pts, vd
+        self.m = m = _model(sd, device)
+        self.flat_pts, self.dirs = pts.reshape(-1, 3).to(device), vd.to(device)
+        self.act = ops.mlp_act_buffer(n * s, True, device)
+        self.x3 = (m._packed_bf16x3(with_bwd=True), m._packed_bwd_bf16x3())
+        self.x2 = (m._packed_f16x2(with_bwd=True), m._packed_bwd_f16x2())
+        with torch.no_grad():
+            self.raw = ops.mlp_forward_f16x2(self.flat_pts, self.dirs, self.x2[0], self.x3[0], True, 5, s, self.act)
+        self.G = T(rng.normal(size=(n * s, 4)).astype(np.float32)).to(device)
+
+    def two(self, G, fallback=True):
+        x3 = self.x3 if fallback else (None, None)
+        d, flags = self.ops.mlp_backward_f16x2(G, self.act, self.m._flat(), *self.x2, *x3, True, 5, want_flags=True)
+        return d.cpu().numpy(), flags.cpu().numpy()
+
+    def three(self, G):
+        return self.ops.mlp_backward_bf16x3(G, self.act, self.m._flat(), *self.x3, True, 5).cpu().numpy()
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def test_two_piece_backward_agrees_with_the_three_piece_kernel_and_fp64(device):
+    """Ordinary gradients: no tile is marked, the parameter gradients behind the two-piece stage are those behind the
+    three-piece stage to a few fp32 roundings of each tensor's scale, and neither is further from an fp64 evaluation
+    than the other by more than that."""
+    sd = _peaky(O.random_state_dict(91), 5.0)
+    c = _Case(device, sd, n=70, s=64)
+    d2, flags = c.two(c.G)
+    d3 = c.three(c.G)
+    assert flags.sum() == 0 and flags.size == (70 * 64 + 127) // 128
+    params = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    (O.query_field(c.pts.double(), c.vd.double(), params) * c.G.cpu().double().reshape(70, 64, 4)).sum().backward()
+    off = 0
+    for k, p in c.m.named_parameters():
+        n = p.numel()
+        a, b = d2[off:off + n].astype(np.float64), d3[off:off + n].astype(np.float64)
+        truth = params[k].grad.reshape(-1).numpy()
+        scale = float(np.abs(truth).max())
+        assert np.abs(a - b).max() <= 4e-6 * scale, (k, np.abs(a - b).max() / scale)
+        e2, e3 = np.abs(a - truth).max() / scale, np.abs(b - truth).max() / scale
+        assert e2 <= max(1.5 * e3, 3e-6), (k, e2, e3)
+        off += n
+    assert off == d2.size
+
+
+def test_every_point_carries_its_own_power_of_two_scale(device):
+    """The stage is linear in each point's upstream gradient and scales it by an exact power of two, so multiplying G by
+    2^-60 or 2^40 multiplies every parameter gradient by exactly that (bit for bit) and marks nothing, and a batch whose
+    points' gradients span sixty orders of magnitude agrees with the three-piece kernel on every tensor."""
+    c = _Case(device, O.random_state_dict(92))
+    base, flags = c.two(c.G)
+    assert flags.sum() == 0
+    for k in (-60, 40):
+        d, flags = c.two(c.G * 2.0 ** k)
+        assert flags.sum() == 0, k
+        assert _same(d, base * np.float32(2.0 ** k)), k
+    rng = np.random.Generator(np.random.PCG64(6))
+    spread = torch.from_numpy((10.0 ** rng.uniform(-35, 25, size=(c.n * c.s, 1))).astype(np.float32)).to(device)
+    d2, flags = c.two(c.G * spread)
+    d3 = c.three(c.G * spread)
+    assert flags.sum() == 0
+    off = 0
+    for k, p in c.m.named_parameters():
+        n = p.numel()
+        scale = float(np.abs(d3[off:off + n]).max())
+        assert np.abs(d2[off:off + n] - d3[off:off + n]).max() <= 4e-6 * scale, k
+        off += n
+    # points without a gradient (and a batch without any) are exact zeros and mark nothing
+    G = c.G.clone()
+    G[128:384] = 0.0
+    d, flags = c.two(G)
+    assert flags.sum() == 0 and np.isfinite(d).all()
+    d, flags = c.two(torch.zeros_like(c.G))
+    assert flags.sum() == 0 and not d.any()
+
+
+def test_gradients_that_leave_the_range_are_redone_by_the_three_piece_kernel(device):
+    """Marked tiles: an infinite or NaN upstream gradient marks its tile (and only that one), a subnormal one too; a
+    layer that grows every gradient by more than 2^7, or a weight outside the range, marks every tile, and the result
+    is then the three-piece stage's bit for bit."""
+    c = _Case(device, O.random_state_dict(93))
+    tiles = c.n * c.s // 128
+    for value in (float("inf"), float("nan")):
+        G = c.G.clone()
+        G[3 * 128 + 5, 1] = value
+        d2, flags = c.two(G)
+        d3 = c.three(G)
+        assert flags.tolist() == [0, 0, 0, 1, 0, 0], value
+        assert np.array_equal(np.isnan(d2), np.isnan(d3)) and np.array_equal(np.isinf(d2), np.isinf(d3)), value
+    G = c.G.clone()
+    G[128:256] *= 1e-42      # subnormal: the scale cannot lift them into range
+    d2, flags = c.two(G)
+    assert flags.tolist() == [0, 1, 0, 0, 0, 0]
+    d3 = c.three(G)
+    scale = np.abs(d3).max()
+    assert np.abs(d2 - d3).max() <= 4e-6 * scale
+
+    for name, edit in (("pts_linears.3.weight", lambda w: w.mul_(4000.0)),
+                       ("pts_linears.5.weight", lambda w: w.__setitem__((5, 70), 1e5)),
+                       ("pts_linears.2.weight", lambda w: w.mul_(1e-6))):
+        sd = O.random_state_dict(93)
+        edit(sd[name])
+        c = _Case(device, sd)
+        d2, flags = c.two(c.G)
+        assert flags.all() and flags.size == tiles, name
+        assert _same(d2, c.three(c.G)), name
+        alone, flags = c.two(c.G, fallback=False)
+        assert flags.all(), name
+
+
+def test_a_default_model_trains_on_the_two_piece_stage(device):
+    """What autograd of a default model's query runs is this stage (and the three-piece one for mlp_dtype 'bf16x3')."""
+    from test_gpu_parity import _query_fn
+    qf = _query_fn()
+    c = _Case(device, O.random_state_dict(94))
+    G = c.G.reshape(c.n, c.s, 4)
+    act3 = c.ops.mlp_act_buffer(c.n * c.s, True, device)     # the three-piece path saves its own forward's activations
+    with torch.no_grad():
+        c.ops.mlp_forward_bf16x3(c.flat_pts, c.dirs, c.x3[0], True, 5, c.s, act3)
+    three = c.ops.mlp_backward_bf16x3(c.G, act3, c.m._flat(), *c.x3, True, 5).cpu().numpy()
+    for dtype, want in (("f32", c.two(c.G)[0]), ("bf16x3", three)):
+        c.m.mlp_dtype = dtype
+        c.m.zero_grad()
+        (qf(c.pts.to(device), c.dirs, c.m) * G).sum().backward()
+        got = torch.cat([p.grad.reshape(-1) for p in c.m.parameters()]).cpu().numpy()
+        assert _same(got, want), dtype

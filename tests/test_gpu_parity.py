@@ -501,12 +501,14 @@ def _grad_close(got, want, what, rtol=2e-3, atol_frac=2e-5):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_frac * scale, err_msg=what)
 
 
-# the two arithmetics a training step can run: split operands on the bf16 matrix instruction (the default), or the fp32
-# matrix instruction throughout
+# the arithmetics a training step can run: split operands on the 16-bit matrix instructions (the default: two fp16 pieces
+# in the forward and backward-data stages, three bf16 pieces in the weight-gradient stage; 'bf16x3': three pieces
+# throughout), or the fp32 matrix instruction throughout
 TRAIN_DTYPES = pytest.mark.parametrize("mlp_dtype", ["f32", "f32_mfma"], ids=["split", "mfma32"])
+TRAIN_DTYPES_ALL = pytest.mark.parametrize("mlp_dtype", ["f32", "bf16x3", "f32_mfma"], ids=["split", "split3", "mfma32"])
 
 
-@TRAIN_DTYPES
+@TRAIN_DTYPES_ALL
 def test_mlp_backward_matches_reference_and_oracle(device, mlp_dtype):
     g = golden("mlp")
     qf = _query_fn()
@@ -554,7 +556,7 @@ def _relu_margin(sd, pts, vd, use_vd):
     return margin.reshape(pts.shape[:-1])
 
 
-@TRAIN_DTYPES
+@TRAIN_DTYPES_ALL
 def test_mlp_backward_sizes_and_no_view_branch(device, mlp_dtype):
     """Ragged point counts (tile padding, empty K slices), the output_linear head, and batches large enough for the
     weight-gradient stage to cut every task into its full number of slices (57,600 and 65,536 points), against oracle
