@@ -287,6 +287,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
             hook()
         timing[0] = True
         ops.PROFILE = None if graphed else []     # events recorded inside a graph cannot be timed
+        ops.MARKED = None if graphed else []
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -298,13 +299,13 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
                 torch.distributed.barrier()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        prof = ops.PROFILE
+        prof, marked = ops.PROFILE, ops.MARKED
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
     finally:     # whatever happened, the next leg starts from the benchmark's weights
-        ops.PROFILE = None
+        ops.PROFILE = ops.MARKED = None
         with torch.no_grad():
             for p, s0 in zip(params, saved):
                 p.copy_(s0)
@@ -321,6 +322,10 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
            "points_per_ray": pts_per_ray, "steps": steps, "final_loss": float(loss.detach()), "mlp_kernels_share_of_step": round(kern / dt, 4),
            "mlp_tflops_algorithmic": round(flop / kern / 1e12, 2) if kern > 0 else None,
            "kernels": train_kernel_rooflines(prof), "hbm_kernels": hbm_kernels(prof)}
+    if marked:   # tiles of 128 points the two-piece stages handed to the three-piece kernels during the timed steps
+        res["marked_tiles"] = {stage: "%d of %d" % (sum(int(f.sum()) for st_, f in marked if st_ == stage),
+                                                    sum(f.numel() for st_, f in marked if st_ == stage))
+                               for stage in ("forward", "backward_data")}
     res.update(held)
     for k in res["kernels"].values():   # the three kernels ran back to back under the same clock and power
         k.update(held)

@@ -17,6 +17,9 @@ from ._lib import check, lib
 # When set to a list, kernel launches append (name, units, start_event, end_event) recorded on the launch stream.
 # units: sample points for the MLP kernels, algorithmic HBM bytes for the streaming kernels.
 PROFILE = None
+# When set to a list, the two-piece MLP stages append (stage, flag words) -- one word per 128-point tile, 1 = the tile left
+# fp16's range and was redone by the three-piece kernel -- so that a caller can count marked tiles after a step.
+MARKED = None
 
 
 class _timed:
@@ -510,6 +513,8 @@ def mlp_forward_f16x2(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], packe
         check(lib.nerf_mlp_fwd_f16x2(n_pts, pts_per_ray, pts.data_ptr(), _ptr(viewdirs) if use_viewdirs else None,
                                      int(use_viewdirs), output_ch, packed.data_ptr(), _ptr(packed_x3), out.data_ptr(), _ptr(act),
                                      flags.data_ptr(), _stream()))
+    if MARKED is not None:
+        MARKED.append(("forward", flags))
     return (out, flags) if want_flags else out
 
 
@@ -634,6 +639,8 @@ def mlp_backward_f16x2(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tenso
         with _timed("mlp_bwd_dw", n_pts):
             check(lib.nerf_mlp_bwd_weights_bf16x3(n_pts, act.data_ptr(), int(use_viewdirs), output_ch, scratch.data_ptr(),
                                                   d_flat.data_ptr(), _stream()))
+    if MARKED is not None:
+        MARKED.append(("backward_data", flags))
     return (d_flat, flags) if want_flags else d_flat
 
 

@@ -240,7 +240,11 @@ def test_graphed_train_step_matches_eager(device):
 def test_optimisation_recovers_a_teacher_scene(device):
     """End to end: images rendered from one pair of networks are the training targets of another pair started from
     different weights; 250 steps of the upstream loop (jittered samples, both losses, Adam) must cut the loss several
-    times over and raise the PSNR -- a check of the gradient path as a whole that per-step parity cannot give."""
+    times over and raise the PSNR -- a check of the gradient path as a whole that per-step parity cannot give.  Along
+    the way the two-piece stages must keep what real gradients look like (transmittance-weighted, zero behind opaque
+    samples, density and colour terms of different size) inside their range: at most 1 % of the 128-point tiles handed to
+    the three-piece kernels, forward and backward."""
+    from nerf_amd import ops
     from nerf_amd.raybatch import ViewSampler
     from nerf_amd.run_nerf import render, run_network
     from nerf_amd.run_nerf_helpers import NeRF, get_embedder, img2mse, mse2psnr
@@ -276,15 +280,26 @@ def test_optimisation_recovers_a_teacher_scene(device):
     opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
     sampler = ViewSampler(images, poses, list(range(5)), H, W, K, 512, device=device, seed=3)
     losses = []
-    for i in range(250):
-        rays, target = sampler.next(i)
-        rgb, _, _, ex = render(H, W, K, chunk=1 << 15, rays=rays, retraw=True, network_fn=student[0], network_fine=student[1],
-                               perturb=1.0, raw_noise_std=0.0, **common)
-        opt.zero_grad()
-        loss = img2mse(rgb, target) + img2mse(ex["rgb0"], target)
-        loss.backward()
-        opt.step()
-        losses.append(float(loss.detach()))
+    ops.MARKED = []
+    try:
+        for i in range(250):
+            rays, target = sampler.next(i)
+            rgb, _, _, ex = render(H, W, K, chunk=1 << 15, rays=rays, retraw=True, network_fn=student[0], network_fine=student[1],
+                                   perturb=1.0, raw_noise_std=0.0, **common)
+            opt.zero_grad()
+            loss = img2mse(rgb, target) + img2mse(ex["rgb0"], target)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        marked = ops.MARKED
+    finally:
+        ops.MARKED = None
+    for stage in ("forward", "backward_data"):
+        flags = torch.cat([f for st, f in marked if st == stage])
+        assert flags.numel() == 250 * (512 * 32 + 512 * 64) // 128, stage
+        share = float(flags.float().mean())
+        print(f"marked tiles, {stage}: {share:.5f}")
+        assert share <= 0.01, (stage, share)
     first, last = np.mean(losses[:10]), np.mean(losses[-10:])
     assert np.isfinite(losses).all()
     assert last < 0.25 * first, (first, last)
