@@ -228,7 +228,8 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
             del kw["ndc"]     # as upstream's create_nerf leaves it for LLFF: render() defaults to ndc=True
         pts_per_ray = 2 * kw["N_samples"] + kw["N_importance"]
         saved = [p.detach().clone() for p in params]
-        opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), capturable=True, fused=True)   # as create_nerf
+        from nerf_amd.optim import FlatAdam
+        opt = FlatAdam(params=params, lr=5e-4, betas=(0.9, 0.999))   # as create_nerf
         stepper = None
         if graphed:
             from nerf_amd.graph_step import GraphedTrainStep

@@ -302,6 +302,20 @@ int nerf_mlp_bwd_data_f16x2(int64_t n_pts, const float* d_out, const float* act,
                             const void* packed_f16x2, const void* packed_bwd_f16x2, const void* packed_bf16x3,
                             const void* packed_bwd_bf16x3, float* scratch, uint32_t* tile_flags, void* stream);
 
+/* torch.optim.Adam's update (what upstream's optimizer.step() runs: run_nerf.py:217-218, 868-881) over up to
+ * nerf_adam_max_runs() runs of parameters in ONE launch.  Run i: counts[i] fp32 elements at params[i], their gradients at
+ * grads[i] and both moments at exp_avg[i] / exp_avg_sq[i] (all DEVICE; the four arrays of pointers and counts are HOST
+ * arrays), updated in place: g += weight_decay * p (if not 0); m = beta1 m + (1 - beta1) g; v = beta2 v + (1 - beta2) g g;
+ * p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps), products and sums in fp64 from the fp32 operands,
+ * every assignment rounded to fp32, as the library optimiser's fused kernel computes them.  t, the count of this update
+ * (1 for the first): step_dev[i] points to run i's count as a DEVICE float (the caller increments it beforehand; a graph
+ * replay then reads the current value), or step_dev = NULL (or an entry NULL) and `step` is used.  lr_dev: the learning
+ * rate as a DEVICE float, or NULL and `lr` is used.  amsgrad / maximize are not covered. */
+int nerf_adam_max_runs(void);
+int nerf_adam_step(int n_runs, const int64_t* counts, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const float* const* step_dev, float step, const float* lr_dev, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, void* stream);
+
 /* ---- nn.Linear for network shapes the fused kernels do not cover --------------------------------------------------
  * (other --netdepth / --netwidth / --multires, --i_embed -1: NeRF.forward layer by layer, run_nerf_helpers.py:109-133,
  * and autograd of it), fp32 on the fp32 matrix instruction; all pointers DEVICE, row-major, ld* = row strides in floats.

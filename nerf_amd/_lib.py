@@ -26,6 +26,7 @@ _p = ctypes.c_void_p
 _i = ctypes.c_int
 _l = ctypes.c_int64
 _f = ctypes.c_float
+_d = ctypes.c_double
 
 SIGNATURES = {
     "nerf_version": (_i, []),
@@ -65,6 +66,8 @@ SIGNATURES = {
     "nerf_mlp_packed_f16x2_bytes": (_l, [_i]),
     "nerf_mlp_f16x2_tile_points": (_l, []),
     "nerf_pack_weights_f16x2": (_i, [_i, _i, _p, _p, _p]),
+    "nerf_adam_max_runs": (_i, []),
+    "nerf_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _d, _d, _d, _d, _d, _p]),
     "nerf_gather_split2": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "nerf_mlp_packed_bwd_f16x2_bytes": (_l, [_i]),
     "nerf_pack_weights_bwd_f16x2": (_i, [_i, _i, _p, _p, _p]),

@@ -209,10 +209,11 @@ def create_nerf(args):
         if net is not None and net.fused_arch():
             net.adopt_flat()
 
-    # (fused: the same Adam as one multi-tensor launch per step instead of seven; capturable: the step counters live on
-    # the device, so a step increments them in one launch instead of 48 host-side scalar additions -- 0.5 ms of the
-    # host's 2.6 ms per 1024-ray step -- and the optimiser can be recorded into a HIP graph; same update either way)
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), fused=True, capturable=True)
+    # (torch.optim.Adam with the same state and checkpoint format; the parameters of each network lie back to back, and so
+    # do their gradients, so a step is one launch of the library's Adam kernel over both networks; step counters and,
+    # if it is made a tensor, the learning rate live on the device, so the optimiser can be recorded into a HIP graph)
+    from .optim import FlatAdam
+    optimizer = FlatAdam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
 
     start = 0
     basedir = args.basedir
