@@ -1,4 +1,5 @@
-"""Busy time versus wall time of the kernels in a rocprofv3 kernel_trace.csv (last FRACTION of the trace)."""
+"""Busy time versus wall time of the kernels in a rocprofv3 kernel_trace.csv: python3 tools/trace_gaps.py FILE [FRACTION [END]]
+looks at the launches between 1 - FRACTION and END (default 1.0) of the trace, counted in launches."""
 import csv
 import sys
 from collections import defaultdict
@@ -6,7 +7,8 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-rows = rows[int(len(rows) * (1 - frac)):]
+stop = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+rows = rows[int(len(rows) * (1 - frac)):int(len(rows) * stop)]
 t0, t1 = int(rows[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in rows)
 busy, per, cnt = 0, defaultdict(int), defaultdict(int)
 end = t0
