@@ -1,7 +1,7 @@
 """The optimisation step (run_nerf.py:856-883) recorded into HIP graphs.
 
-At the upstream batch size (N_rand = 1024) a step is about 43 launches, of which six (the MLP kernels) carry 92 % of
-the GPU time; the rest are microsecond kernels.  Eager, the launching thread needs about half the step's 5 ms for them,
+At the upstream batch size (N_rand = 1024) a step is about 49 launches, of which six (the MLP kernels) carry 94 % of
+the GPU time; the rest are microsecond kernels.  Eager, the launching thread needs about half the step's 4.6 ms for them,
 which is fine until the host's cores are contended and the thread falls behind the GPU.  The whole
 step -- render with gradients, the two MSE terms, backward, Adam -- only enqueues work on the current stream, so it can
 be captured once and replayed:
@@ -12,8 +12,8 @@ be captured once and replayed:
 
 Inputs live in fixed buffers (`rays`, `target`) that `step` overwrites before each replay; the loss and PSNR of the
 last step are left in `loss` / `psnr` (device scalars, read them with float() when needed, not every step).
-The optimizer must be capturable (torch.optim.Adam(..., capturable=True)), which also lets the learning rate be a
-device scalar that `set_lr` updates without re-recording.
+The optimizer must be capturable (nerf_amd.optim.FlatAdam, or torch.optim.Adam(..., capturable=True)), which also lets
+the learning rate be a device scalar that `set_lr` updates without re-recording.
 """
 from __future__ import annotations
 

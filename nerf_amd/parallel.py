@@ -5,10 +5,12 @@ The upstream program is single-process; rays are independent, so the two extensi
     rank runs the unchanged single-GPU path on its slice, and ONE all_gather of rgb/disp/acc
     (20 bytes per ray) reassembles the image on every rank;
   * allreduce_gradients: data-parallel training.  Each rank draws its own rays, then the gradients
-    of both networks travel as ONE flat fp32 bucket (2 x 595,844 floats = 4.77 MB) through a single
-    all_reduce(SUM) and are scaled by 1/world_size.  Because the loss is a mean over equally sized
-    shards, the result equals the gradient of the world_size-times larger batch.  At this size the
-    collective is latency-bound over xGMI; one bucket means one latency.
+    are summed over the ranks and scaled by 1/world_size.  The fused MLP's backward leaves the
+    gradients of a network as views of ONE flat vector (595,844 floats = 2.38 MB), so each network's
+    vector is all-reduced where it lies (one collective per network, no concatenation, no copy back);
+    gradients laid out any other way travel as one concatenated bucket.  Because the loss is a mean
+    over equally sized shards, the result equals the gradient of the world_size-times larger batch.
+    At this size the collectives are latency-bound over xGMI.
 Both work on any backend (the CPU tests use gloo).
 """
 from __future__ import annotations

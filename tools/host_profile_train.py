@@ -25,7 +25,8 @@ H = W = 400
 K = bench.lego_camera(H, W)
 kw = dict(kwargs, perturb=1.0, raw_noise_std=0.0)
 params = list(models[0].parameters()) + list(models[1].parameters())
-opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999), fused=True, capturable=True)
+from nerf_amd.optim import FlatAdam  # noqa: E402
+opt = FlatAdam(params=params, lr=5e-4, betas=(0.9, 0.999))
 poses = torch.stack([bench.orbit_pose(t) for t in (0.0, 45.0, 90.0, 135.0)], 0)
 images = torch.rand(4, H, W, 3, device=dev)
 sampler = ViewSampler(images, poses, list(range(4)), H, W, K, n_rand, device=dev, seed=1)
