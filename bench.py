@@ -180,10 +180,10 @@ def hbm_kernels(prof):
 
 
 # algorithmic FLOP per sample point of the MLP kernels of a train step, and how many 16-bit matrix instructions each
-# issues per fp32-accurate product: the forward and backward-data run on two fp16 pieces per operand (three
-# instructions), the weight gradients on three bf16 pieces (six)
+# issues per fp32-accurate product: all three stages run on two fp16 pieces per operand (three instructions; "mlp_bwd" is the
+# one-call three-piece pass, six)
 TRAIN_KERNEL_FLOP = {"mlp_fwd_save": 1186816, "mlp_bwd_data": 1115392, "mlp_bwd_dw": 1186816, "mlp_bwd": 2302208}
-TRAIN_KERNEL_PRODUCTS = {"mlp_fwd_save": PAIR_PRODUCTS, "mlp_bwd_data": PAIR_PRODUCTS, "mlp_bwd_dw": SPLIT_PRODUCTS, "mlp_bwd": SPLIT_PRODUCTS}
+TRAIN_KERNEL_PRODUCTS = {"mlp_fwd_save": PAIR_PRODUCTS, "mlp_bwd_data": PAIR_PRODUCTS, "mlp_bwd_dw": PAIR_PRODUCTS, "mlp_bwd": SPLIT_PRODUCTS}
 
 
 def train_kernel_rooflines(prof):

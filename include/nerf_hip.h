@@ -294,13 +294,34 @@ int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdir
  * recomputed by the three-piece kernel in a second launch on the same stream; with both NULL only the first launch runs.
  * packed_f16x2: the forward stream of nerf_pack_weights_f16x2 (its fp32 tables and range words are read);
  * packed_bwd_f16x2: nerf_mlp_packed_bwd_f16x2_bytes() bytes built by nerf_pack_weights_bwd_f16x2 (W^T of the layers as
- * pairs of 1 KiB A-operand blocks hi | lo), or the second stream of nerf_gather_split2.  The weight-gradient stage
- * that follows is nerf_mlp_bwd_weights_bf16x3. */
+ * pairs of 1 KiB A-operand blocks hi | lo), or the second stream of nerf_gather_split2.
+ * tile_max (DEVICE, NERF_DY_STAGES words per tile, caller-owned, need not be initialised; or NULL): per tile and group of dY
+ * rows, the largest magnitude stored, as exponent bits + 1 (0 = all zeros) -- what nerf_mlp_bwd_weights_f16x2 takes its
+ * scales from.  The weight-gradient stage that follows is nerf_mlp_bwd_weights_f16x2 or nerf_mlp_bwd_weights_bf16x3. */
+#define NERF_DY_STAGES 18
+#define NERF_DW_CTL_WORDS 24
 int64_t nerf_mlp_packed_bwd_f16x2_bytes(int use_viewdirs);
 int nerf_pack_weights_bwd_f16x2(int use_viewdirs, int output_ch, const float* params, void* packed_bwd_f16x2, void* stream);
 int nerf_mlp_bwd_data_f16x2(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                             const void* packed_f16x2, const void* packed_bwd_f16x2, const void* packed_bf16x3,
-                            const void* packed_bwd_bf16x3, float* scratch, uint32_t* tile_flags, void* stream);
+                            const void* packed_bwd_bf16x3, float* scratch, uint32_t* tile_flags, uint32_t* tile_max,
+                            void* stream);
+
+/* The weight-gradient stage on the fp16 matrix instruction, three matrix instructions per product into one accumulator
+ * (same act / scratch / d_params as nerf_mlp_bwd_weights_bf16x3; dW = dY X^T of autograd, run_nerf_helpers.py:109-133
+ * backwards).  dY is multiplied by one power of two per group of rows and batch (from tile_max: the group's largest
+ * magnitude goes to [2^13, 2^14)) and split into fp16(x), fp16(x - hi) and fp16(x) * 2^-11; the activations into
+ * fp16(x) and fp16((x - hi) * 2^11); product = hi.hi + residual.hi + (hi * 2^-11).lo.  Every activation keeps 22 bits of
+ * its own magnitude; the gradient side is exact to 2^-39 of the group's largest gradient in the batch (full relative
+ * precision over 17 octaves below it).  Error of a product against fp64 below an fp32 accumulation's of the same sum,
+ * relative to the product's largest entry; a unit whose gradients stay a million times below its layer's largest for
+ * the whole batch keeps about five digits (nerf_mlp_bwd_weights_bf16x3 keeps all of them).  If any word of fwd_flags (the tile flags of
+ * nerf_mlp_fwd_f16x2 for these points, or NULL) or bwd_flags (those of nerf_mlp_bwd_data_f16x2) is set, the three-piece
+ * kernel computes the whole batch instead; the choice is made on the device (both kernels are launched, one returns at
+ * once), nothing synchronises.  ctl: NERF_DW_CTL_WORDS words of DEVICE workspace. */
+int nerf_mlp_bwd_weights_f16x2(int64_t n_pts, const float* act, int use_viewdirs, int output_ch, float* scratch,
+                               float* d_params, const uint32_t* fwd_flags, const uint32_t* bwd_flags, const uint32_t* tile_max,
+                               uint32_t* ctl, void* stream);
 
 /* torch.optim.Adam's update (what upstream's optimizer.step() runs: run_nerf.py:217-218, 868-881) over up to
  * nerf_adam_max_runs() runs of parameters in ONE launch.  Run i: counts[i] fp32 elements at params[i], their gradients at

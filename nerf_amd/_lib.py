@@ -71,7 +71,8 @@ SIGNATURES = {
     "nerf_gather_split2": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "nerf_mlp_packed_bwd_f16x2_bytes": (_l, [_i]),
     "nerf_pack_weights_bwd_f16x2": (_i, [_i, _i, _p, _p, _p]),
-    "nerf_mlp_bwd_data_f16x2": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_mlp_bwd_data_f16x2": (_i, [_l, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_mlp_bwd_weights_f16x2": (_i, [_l, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_mlp_fwd_f16x2": (_i, [_l, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "nerf_mlp_packed_bwd_bf16x3_bytes": (_l, [_i]),
     "nerf_pack_weights_bwd_bf16x3": (_i, [_i, _i, _p, _p, _p]),

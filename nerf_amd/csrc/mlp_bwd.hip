@@ -520,6 +520,29 @@ int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdir
     return nerfdw::run_dw_x3(ldp, use_viewdirs, output_ch, act, scratch, slabs, slab, d_params, stream);
 }
 
+static_assert(nerfdw::DY_STAGES == NERF_DY_STAGES && nerfdw::DW_CTL_WORDS == NERF_DW_CTL_WORDS, "include/nerf_hip.h and mlp_dw.hpp");
+
+int nerf_mlp_bwd_weights_f16x2(int64_t n_pts, const float* act, int use_viewdirs, int output_ch, float* scratch,
+                               float* d_params, const uint32_t* fwd_flags, const uint32_t* bwd_flags, const uint32_t* tile_max,
+                               uint32_t* ctl, void* stream_) {
+    NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd_weights_f16x2: n_pts=%lld", (long long)n_pts);
+    NERF_REQUIRE(d_params, "nerf_mlp_bwd_weights_f16x2: null d_params");
+    NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd_weights_f16x2: output_ch=%d not in 1..8", output_ch);
+    hipStream_t stream = as_stream(stream_);
+    const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
+    if (n_pts == 0) {
+        hipError_t e0 = hipMemsetAsync(d_params, 0, po.total * sizeof(float), stream);
+        return e0 == hipSuccess ? 0 : fail(NERF_E_LAUNCH, "nerf_mlp_bwd_weights_f16x2: memset: %s", hipGetErrorString(e0));
+    }
+    NERF_REQUIRE(act && scratch && bwd_flags && tile_max && ctl, "nerf_mlp_bwd_weights_f16x2: null pointer");
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0,
+                 "nerf_mlp_bwd_weights_f16x2: buffers must be 16-byte aligned");
+    const int64_t ldp = padded_points(n_pts);
+    const int64_t slab = slab_floats(use_viewdirs, output_ch);
+    float* slabs = scratch + (int64_t)scr_rows(use_viewdirs) * ldp;
+    return nerfdw::run_dw_x2(ldp, use_viewdirs, output_ch, act, scratch, slabs, slab, d_params, fwd_flags, bwd_flags, tile_max, ctl, stream);
+}
+
 int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                         const void* packed_x3, const void* packed_bwd_x3, float* scratch, float* d_params, void* stream_) {
     NERF_REQUIRE(d_params, "nerf_mlp_bwd_bf16x3: null d_params");

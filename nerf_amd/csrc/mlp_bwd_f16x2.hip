@@ -17,6 +17,7 @@
 #include "mlp_bf16_layout.hpp"
 #include "mlp_bwd16_layout.hpp"
 #include "mlp_x2.hpp"
+#include "mlp_dw.hpp"
 
 using namespace nerfhip;
 using namespace nerflayout;
@@ -30,17 +31,18 @@ namespace {
 
 constexpr int SCALE_TARGET = 8;        // a point's largest value is moved to [2^8, 2^9)
 constexpr int SCALE_LIMIT = 120;       // |scale exponent|: 2^k and 2^-k stay normal floats
+constexpr int BWD_STAGES = nerfdw::DY_STAGES;
 
 // One backward-data layer: out = keep(start + M in), M = the section's W^T; `in` carries the point's scale 2^k.
 // keep (MASK): as layer_x3b of mlp_bwd_bf16x3.hip.  ALPHA: start = d_sigma (at the input's scale) times the density
 // head's weight column.  A finished value is stored times down[ct] = 2^-k to srow[ct] (+ 4 t row groups) and, with
 // STORE, split times rs[ct] (the move to the next scale) into the pieces of fragment t / 2 of OUT; mx[ct] collects the
-// largest leading piece as fp16 bits.
+// largest leading piece as fp16 bits, stored[ct] the largest magnitude stored (unscaled).
 template <int NOUT, int NKS, bool MASK, bool ALPHA, bool STORE, typename InFrag>
 __device__ __forceinline__ void layer_x2b(Stream2& st, int lane, int g, const char*& cur, InFrag in_frag,
                                           u32x4 (&OUT)[2][NCT2][8], const float* alpha_g, const float (&d_sigma)[NCT2],
                                           const u32x4 (&mw)[NCT2], float* (&srow)[NCT2], const float (&down)[NCT2],
-                                          const float (&rs)[NCT2], uint32_t (&mx)[NCT2]) {
+                                          const float (&rs)[NCT2], uint32_t (&mx)[NCT2], float (&stored)[NCT2]) {
     constexpr int NB = NOUT * NKS, DEPTH = 3, NPIECE = 4 * NCT2;
     constexpr int PPS = (NPIECE + (NKS < 8 ? NKS : 8) - 1) / (NKS < 8 ? NKS : 8);   // epilogue values per k-step
     u32x4 abuf[DEPTH + 1][2];
@@ -59,6 +61,7 @@ __device__ __forceinline__ void layer_x2b(Stream2& st, int lane, int g, const ch
             v = on ? v : 0.0f;
         }
         sv[r] = v * down[ct];
+        stored[ct] = __builtin_fmaxf(stored[ct], __builtin_fabsf(sv[r]));
         if constexpr (r == 3) *reinterpret_cast<f32x4*>(srow[ct] + 4 * TP * GROUP_FLOATS) = sv;
         if constexpr (STORE) {
             const float vs = v * rs[ct];
@@ -126,11 +129,12 @@ template <bool VIEWDIRS>
 __global__ void __launch_bounds__(X2_THREADS, 1)
 k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_out, const float* __restrict__ act,
                      const char* __restrict__ packed_fwd, const char* __restrict__ packed_bwd, float* __restrict__ scr,
-                     uint32_t* __restrict__ tile_flags) {
+                     uint32_t* __restrict__ tile_flags, uint32_t* __restrict__ tile_max) {
     extern __shared__ __attribute__((aligned(16))) char smem2b[];
     char* ring = smem2b;
     float* aux = reinterpret_cast<float*>(smem2b + RING2_BYTES);
     uint32_t* wave_flags = reinterpret_cast<uint32_t*>(smem2b + RING2_BYTES + AUX16_FLOATS * 4);
+    uint32_t* stage_max = wave_flags + X2_WAVES;      // per wave and stage: the largest stored magnitude, as exponent bits + 1
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
     constexpr int UV = VIEWDIRS ? 1 : 0;
     const char* tail = packed_fwd + (int64_t)x2_stream_slabs(UV) * SLAB2_BYTES;
@@ -172,6 +176,7 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
     st.g = packed_bwd + wave * WAVE_BLOCKS2 * 1024 + lane * 16;
     st.next = 0;
     st.nslabs = bwd16_stream_blocks(UV) / SLABP;
+    for (int i = tid; i < X2_WAVES * BWD_STAGES; i += X2_THREADS) stage_max[i] = 0u;
     __syncthreads();
     st.fetch(0);
     st.fetch(1);
@@ -228,10 +233,12 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
             bool have = e16 != 0;
             if (ea != 0 && ea != 255) {                           // the same exponent for the other term, at the current scale
                 const int et = ea - 127 + kexp[ct] + 15;
-                if (!have || et > e) e = et > 30 ? 30 : et;
+                if (!have || et > e) e = et;
                 have = true;
             }
-            int kn = (have && e16 != 31) ? kexp[ct] + (SCALE_TARGET + 15 - e) : kexp[ct];
+            int d = (have && e16 != 31) ? SCALE_TARGET + 15 - e : 0;
+            d = d > 100 ? 100 : (d < -100 ? -100 : d);            // (one move stays a normal float)
+            int kn = kexp[ct] + d;
             kn = kn > SCALE_LIMIT ? SCALE_LIMIT : (kn < -SCALE_LIMIT ? -SCALE_LIMIT : kn);
             down[ct] = pow2i(-kexp[ct]);
             up_in[ct] = pow2i(kexp[ct]);
@@ -241,6 +248,32 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
         }
     };
 
+    // the largest magnitude this stage stored for the weight-gradient stage, per tile: an upper bound 2^(e - 127) with
+    // e = exponent bits + 1 (0: nothing but zeros), collected over the workgroup in LDS
+    float stored[NCT2] = {0.0f, 0.0f};
+    // (the wave's largest word by bisection over ballots: scalar work, no LDS traffic; 64 lanes' atomics on one LDS word
+    // took 1.6 us apiece)
+    auto wave_max = [&](uint32_t e) -> uint32_t {            // e < 512
+        uint32_t best = 0u;
+#pragma unroll
+        for (int bit = 8; bit >= 0; --bit) {
+            const uint32_t cand = best | (1u << bit);
+            if (__ballot(e >= cand) != 0ull) best = cand;
+        }
+        return best;
+    };
+    auto put_stage = [&](int stage, uint32_t e) {
+        const uint32_t m = wave_max(e);
+        if (lane == 0) stage_max[wave * BWD_STAGES + stage] = m;
+    };
+    auto word = [](float v) -> uint32_t {                    // exponent bits + 1, 0 for a zero
+        const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+        return b != 0u ? (b >> 23) + 1u : 0u;
+    };
+    auto record = [&](int stage) {
+        put_stage(stage, word(__builtin_fmaxf(stored[0], stored[1])));
+        stored[0] = stored[1] = 0.0f;
+    };
     u32x4 X[2][NCT2][8], Y[2][NCT2][8];
     auto fromX = [&]<int ct, int ks, int s>() -> u32x4 { return X[s][ct][ks]; };
     auto fromY = [&]<int ct, int ks, int s>() -> u32x4 { return Y[s][ct][ks]; };
@@ -252,7 +285,10 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
     auto put = [&]<int ct, int t>(const f32x4& v) {
         f32x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = v[i] * down[ct];
+        for (int i = 0; i < 4; ++i) {
+            o[i] = v[i] * down[ct];
+            stored[ct] = __builtin_fmaxf(stored[ct], __builtin_fabsf(o[i]));
+        }
         *reinterpret_cast<f32x4*>(sr[ct] + 4 * t * GROUP_FLOATS) = o;
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
@@ -276,10 +312,21 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
                 *reinterpret_cast<f32x4*>(st_ + (SCR_HEAD / 4) * GROUP_FLOATS + pw[ct] * 4) = ga;
                 *reinterpret_cast<f32x4*>(st_ + (SCR_HEAD2 / 4) * GROUP_FLOATS + pw[ct] * 4) = gb;
             }
-            start_scale(ct, run_max(run_max(0.0f, gd[ct][0], gd[ct][1]), gd[ct][2], gd[ct][3]));
+            stored[ct] = run_max(run_max(0.0f, gd[ct][0], gd[ct][1]), gd[ct][2], gd[ct][3]);
+            // the first two layers see the colour terms only; the density term joins two layers down, where it takes part
+            // in that layer's scale (check): a point starts at the scale of its colour terms if it has any
+            const float m_rgb = run_max(run_max(0.0f, gd[ct][0], gd[ct][1]), gd[ct][2], 0.0f);
+            start_scale(ct, m_rgb != 0.0f ? m_rgb : stored[ct]);
+            stored[ct] = 0.0f;
+        }
+        // one word per channel of dL/d(raw): colour 0..2, density 4 (every lane group holds the same values)
+        static_for<4>([&]<int c>() {
+            put_stage(c == 3 ? 4 : c, word(run_max(0.0f, gd[0][c], gd[1][c])));
+        });
+#pragma unroll
+        for (int ct = 0; ct < NCT2; ++ct)
 #pragma unroll
             for (int i = 0; i < 3; ++i) gd[ct][i] *= up_in[ct];
-        }
         // views layer: d(hidden) = Wrgb^T d_rgb, masked -> X fragments 0..3, stored
         load_masks(8);
         rows(SCR_VIEWS);
@@ -299,9 +346,11 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
             });
         });
         check(none);
+        record(nerfdw::DY_STAGE_VIEWS);
         // d(feature) = Wviews[:, :256]^T dY_views -> Y (feature_linear has no activation)
         rows(SCR_FEAT);
-        layer_x2b<16, 4, false, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx);
+        layer_x2b<16, 4, false, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+        record(nerfdw::DY_STAGE_FEAT);
         {   // the density head's term of the next layer: its largest entry per point
             float wa = 0.0f;
 #pragma unroll
@@ -318,8 +367,9 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
         for (int ct = 0; ct < NCT2; ++ct) dsig_in[ct] = d_sigma[ct] * up_in[ct];
         load_masks(7);
         rows(SCR_H0 + 7 * 256);
-        layer_x2b<16, 8, true, true, true>(st, lane, g, cur, fromY, X, hw + 4 * g, dsig_in, mw, sr, down, rs, mx);
+        layer_x2b<16, 8, true, true, true>(st, lane, g, cur, fromY, X, hw + 4 * g, dsig_in, mw, sr, down, rs, mx, stored);
         check(none);
+        record(nerfdw::dy_stage_layer(7));
     } else {
         // d(h7) = Wout^T d_out, masked -> X, stored
         float gd[NCT2][8];
@@ -337,9 +387,12 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
                 *reinterpret_cast<f32x4*>(st_ + (SCR_HEAD / 4 + 1) * GROUP_FLOATS + pw[ct] * 4) = gb;
             }
             start_scale(ct, m);
+        }
+        static_for<8>([&]<int c>() { put_stage(c, word(run_max(0.0f, gd[0][c], gd[1][c]))); });
+#pragma unroll
+        for (int ct = 0; ct < NCT2; ++ct)
 #pragma unroll
             for (int c = 0; c < 8; ++c) gd[ct][c] *= up_in[ct];
-        }
         load_masks(7);
         rows(SCR_H0 + 7 * 256);
         static_for<16>([&]<int t>() {
@@ -357,35 +410,43 @@ k_mlp_bwd_data_f16x2(int64_t n_pts, int output_ch, const float* __restrict__ d_o
             });
         });
         check(none);
+        record(nerfdw::dy_stage_layer(7));
     }
 
     // dY of pts layers 6 .. 0: X (layer l + 1) -> Y (layer l) -> X (layer l - 1) ...
     load_masks(6); rows(SCR_H0 + 6 * 256);
-    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx);
-    check(none);
+    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+    check(none); record(nerfdw::dy_stage_layer(6));
     load_masks(5); rows(SCR_H0 + 5 * 256);
-    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromY, X, nullptr, dsig_in, mw, sr, down, rs, mx);
-    check(none);
+    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromY, X, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+    check(none); record(nerfdw::dy_stage_layer(5));
     load_masks(4); rows(SCR_H0 + 4 * 256);
-    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx);
-    check(none);
+    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+    check(none); record(nerfdw::dy_stage_layer(4));
     load_masks(3); rows(SCR_H0 + 3 * 256);
-    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromY, X, nullptr, dsig_in, mw, sr, down, rs, mx);
-    check(none);
+    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromY, X, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+    check(none); record(nerfdw::dy_stage_layer(3));
     load_masks(2); rows(SCR_H0 + 2 * 256);
-    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx);
-    check(none);
+    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+    check(none); record(nerfdw::dy_stage_layer(2));
     load_masks(1); rows(SCR_H0 + 1 * 256);
-    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromY, X, nullptr, dsig_in, mw, sr, down, rs, mx);
-    check(none);
+    layer_x2b<16, 8, true, false, true>(st, lane, g, cur, fromY, X, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+    check(none); record(nerfdw::dy_stage_layer(1));
     load_masks(0); rows(SCR_H0);
-    layer_x2b<16, 8, true, false, false>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx);
+    layer_x2b<16, 8, true, false, false>(st, lane, g, cur, fromX, Y, nullptr, dsig_in, mw, sr, down, rs, mx, stored);
+    record(nerfdw::dy_stage_layer(0));
 
     // one flag per 128-point tile: any lane of any wave that left the range
     const bool wave_bad = __any(bad);
     if (lane == 0) wave_flags[wave] = wave_bad ? 1u : 0u;
     __syncthreads();
     if (tid == 0) tile_flags[blockIdx.x] = wave_flags[0] | wave_flags[1] | wave_flags[2] | wave_flags[3];
+    if (tile_max != nullptr && tid < BWD_STAGES) {
+        uint32_t m = stage_max[tid];
+#pragma unroll
+        for (int w = 1; w < X2_WAVES; ++w) m = stage_max[w * BWD_STAGES + tid] > m ? stage_max[w * BWD_STAGES + tid] : m;
+        tile_max[(int64_t)blockIdx.x * BWD_STAGES + tid] = m;
+    }
 }
 
 // flat parameters -> transposed stream of pairs
@@ -404,7 +465,7 @@ __global__ void __launch_bounds__(256) k_pack_x2b(int use_viewdirs, int output_c
     }
 }
 
-constexpr size_t X2B_LDS_BYTES = RING2_BYTES + AUX16_FLOATS * sizeof(float) + X2_WAVES * sizeof(uint32_t);
+constexpr size_t X2B_LDS_BYTES = RING2_BYTES + AUX16_FLOATS * sizeof(float) + (X2_WAVES + X2_WAVES * BWD_STAGES) * sizeof(uint32_t);
 
 }  // namespace
 
@@ -428,7 +489,7 @@ int nerf_pack_weights_bwd_f16x2(int use_viewdirs, int output_ch, const float* pa
 
 int nerf_mlp_bwd_data_f16x2(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                             const void* packed_f16x2, const void* packed_bwd_f16x2, const void* packed_x3,
-                            const void* packed_bwd_x3, float* scratch, uint32_t* tile_flags, void* stream_) {
+                            const void* packed_bwd_x3, float* scratch, uint32_t* tile_flags, uint32_t* tile_max, void* stream_) {
     NERF_REQUIRE(n_pts >= 0, "nerf_mlp_bwd_data_f16x2: n_pts=%lld", (long long)n_pts);
     NERF_REQUIRE(use_viewdirs || (output_ch >= 1 && output_ch <= 8), "nerf_mlp_bwd_data_f16x2: output_ch=%d not in 1..8", output_ch);
     if (n_pts == 0) return 0;
@@ -447,7 +508,7 @@ int nerf_mlp_bwd_data_f16x2(int64_t n_pts, const float* d_out, const float* act,
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_data_f16x2: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X2_THREADS), X2B_LDS_BYTES, stream, n_pts, och, d_out, act,
                            reinterpret_cast<const char*>(packed_f16x2), reinterpret_cast<const char*>(packed_bwd_f16x2), scratch,
-                           tile_flags);
+                           tile_flags, tile_max);
         return launched("nerf_mlp_bwd_data_f16x2");
     };
     int rc = use_viewdirs ? go(k_mlp_bwd_data_f16x2<true>, 4) : go(k_mlp_bwd_data_f16x2<false>, output_ch);

@@ -34,4 +34,20 @@ int reduce_regions(const SlabRegions& regions, const float* slabs, int64_t slab_
 int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
               float* d_params, hipStream_t stream);
 
+// ---- the two-piece form of the same stage (mlp_dw_x3.hip, k_dw_x3<true>) ----------------------------------------
+// The two-piece backward-data kernel (mlp_bwd_f16x2.hip) leaves, per 128-point tile, DY_STAGES words: the largest
+// magnitude it stored for each group of dY rows as exponent bits + 1 (0 = nothing but zeros).  Stages 0..7: the head
+// rows, one per channel of dL/d(raw) (view branch: 0..2 colour, 4 density); 8: view layer; 9: feature layer; 17 - l:
+// pts layer l.  One small kernel turns them, and the tile
+// flags of both two-piece stages, into DW_CTL_WORDS control words: [0] = 1 if any tile was marked (the two-piece
+// weight-gradient kernel then leaves the whole batch to the three-piece one), [1 + stage] = the power of two that
+// takes the stage's largest magnitude to 2^14 (as a biased exponent: the float 2^k has the bits word << 23).
+constexpr int DY_STAGES = 18;
+constexpr int DW_CTL_WORDS = 24;
+constexpr int DY_STAGE_VIEWS = 8, DY_STAGE_FEAT = 9;
+constexpr int dy_stage_layer(int l) { return 17 - l; }
+int run_dw_x2(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
+              float* d_params, const uint32_t* fwd_flags, const uint32_t* bwd_flags, const uint32_t* tile_max, uint32_t* ctl,
+              hipStream_t stream);
+
 }  // namespace nerfdw

@@ -27,9 +27,24 @@
 // what the full kernel lacks); row-tile fragments not read ahead (12.4 ms); temporal instead of non-temporal loads (12.5 ms).
 // Bias gradients are fp32 row sums of dY taken in the staging path.  Partial results go to per-slice slabs that a last
 // kernel sums in fixed order (bitwise reproducible, no float atomics).
+//
+// The same kernel in a TWO-piece form (k_dw_x3<true>) on v_mfma_f32_32x32x16_f16, three matrix instructions per tile
+// pair and stage into the SAME single accumulator (a second one, as the forward's two-piece scheme keeps, would be the
+// whole register file for a 256 x 256 tile).  The gradient operand is scaled by ONE power of two per group of dY rows
+// and batch -- taken from the maxima the two-piece backward-data kernel leaves per tile, so that the group's largest
+// magnitude lies in [2^13, 2^14) -- and split into hi = fp16(x), the unscaled residual fp16(x - hi), and hi * 2^-11; the
+// activation operand into hi = fp16(x) and lo = fp16((x - hi) * 2^11); the product is hi.hi + residual.hi +
+// (hi * 2^-11).lo.  Every activation keeps 22 bits of ITS OWN magnitude (the scaled low piece; activations have no
+// common scale: a unit may stay at 1e-5 for a whole batch).  The two extra gradient-side pieces are exact to 2^-25
+// absolute = 2^-39 of the group's largest gradient in the batch: full relative precision over 17 octaves below that
+// largest value, and below it an error that any sum with a term near the top does not see (a unit whose gradients
+// stay a million times below its layer's largest for the whole batch keeps about five digits).  Any tile marked
+// by the two-piece forward or backward-data kernels sends the whole batch to the three-piece form (decided on the
+// device: both forms are launched, one of them returns at once).
 #include "common.hpp"
 #include "mlp_core.hpp"
 #include "mlp_x3.hpp"
+#include "mlp_x2.hpp"
 #include "mlp_dw.hpp"
 
 using namespace nerfhip;
@@ -51,10 +66,11 @@ static_assert(NSETS == 2 || NSETS == 3, "the stage loop is written for two or th
 // What a kind of task looks like to a workgroup.  The LDS image holds 128 * NL operand rows per point: the dY rows
 // first (A_TILES tiles of 32), then the input rows; a wave multiplies TM row tiles by TN column tiles (32 x 32 each).
 template <int KIND> struct DwKind;
-template <> struct DwKind<0> { static constexpr int NL = 4, A_TILES = 8, TM = 4, TN = 2, NBIAS = 2; };    // hidden layer 256 x 256
-template <> struct DwKind<1> { static constexpr int NL = 5, A_TILES = 16, TM = 2, TN = 2, NBIAS = 2; };   // dY0 ++ dY5 x encoded position
-template <> struct DwKind<2> { static constexpr int NL = 4, A_TILES = 4, TM = 1, TN = 5, NBIAS = 1; };    // views layer x (feature ++ direction)
-template <> struct DwKind<3> { static constexpr int NL = 3, A_TILES = 4, TM = 1, TN = 1, NBIAS = 1; };    // heads: <= 8 rows
+// NGRAD: the first NGRAD loads are dY rows, the others saved activations.
+template <> struct DwKind<0> { static constexpr int NL = 4, A_TILES = 8, TM = 4, TN = 2, NBIAS = 2, NGRAD = 2; };    // hidden layer 256 x 256
+template <> struct DwKind<1> { static constexpr int NL = 5, A_TILES = 16, TM = 2, TN = 2, NBIAS = 2, NGRAD = 4; };   // dY0 ++ dY5 x encoded position
+template <> struct DwKind<2> { static constexpr int NL = 4, A_TILES = 4, TM = 1, TN = 5, NBIAS = 1, NGRAD = 1; };    // views layer x (feature ++ direction)
+template <> struct DwKind<3> { static constexpr int NL = 3, A_TILES = 4, TM = 1, TN = 1, NBIAS = 1, NGRAD = 1; };    // heads: <= 8 rows
 
 template <int NL> struct Image {
     static constexpr int ROWS = 128 * NL;
@@ -72,6 +88,7 @@ struct DwxTask {
     int ld_src[MAX_LOADS];     // per load of 32 row groups: 0 = gradient workspace, 1 = saved activations
     int ld_grp[MAX_LOADS];     // first row group
     int ld_n[MAX_LOADS];       // valid row groups (the others repeat the first: nothing reads them)
+    int ld_stage[MAX_LOADS];   // dY loads: which group of dY rows (mlp_dw.hpp), i.e. which scale of the two-piece form
     int M, N;                  // valid rows / columns of the product(s)
     int ldc, ldc2;             // row strides in the flat parameter vector
     int64_t out, out2;         // W[0][0] of the product, and of the second one (kind 1: layer 5's encoded-input columns)
@@ -90,16 +107,38 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_sh
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x16 mfma32h(bf16x8 a, bf16x8 b, f32x16 c) {     // the same 16 bytes read as eight fp16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(nerfx2::f16x8, a), __builtin_bit_cast(nerfx2::f16x8, b), c, 0, 0, 0);
+}
+// two values -> hi = fp16 pair, lo = the pair of UNSCALED residuals fp16(v - hi) (one mixed fused multiply-add each)
+__device__ __forceinline__ void split2u_pair(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+    const nerfx2::f16x2 h = {(_Float16)v0, (_Float16)v1};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float c = -1.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi), "v"(c), "v"(v0), "v"(v1));
+}
 // position of 8-byte chunk `c` (four rows) inside its 64-byte group for point `pt`
 __device__ __forceinline__ int swz(int c, int pt) { return c ^ (((pt >> 1) & 3) << 1); }
 
-template <int KIND>
+template <int KIND, bool TWO>
 __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t nchunks, int64_t tile_floats,
                                          const float* __restrict__ act, const float* __restrict__ scr,
-                                         float* __restrict__ slab, char* smem) {
+                                         float* __restrict__ slab, char* smem, const uint32_t* __restrict__ ctl) {
     using K = DwKind<KIND>;
     using Im = Image<K::NL>;
-    constexpr int NL = K::NL, TM = K::TM, TN = K::TN, NBIAS = K::NBIAS;
+    constexpr int NL = K::NL, TM = K::TM, TN = K::TN, NBIAS = K::NBIAS, NGRAD = K::NGRAD;
+    constexpr int NPB = TWO ? 2 : 3;                 // pieces of an activation fragment (a dY fragment has 3 either way)
+    // two-piece form: the power of two each dY load is multiplied by, and the one this wave's block is divided by
+    // (a head task, KIND 3: its rows are channels of dL/d(raw), each with a scale of its own, stages ld_stage[0] + row)
+    float up[NGRAD];
+    float up_row[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    float out_scale = 1.0f;
+    if constexpr (TWO) {
+#pragma unroll
+        for (int k = 0; k < NGRAD; ++k) up[k] = __uint_as_float(ctl[1 + task.ld_stage[k]] << 23);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
 
@@ -111,6 +150,7 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     int a_tile0, b_tile0, row0, col0, ldc = task.ldc;
     int64_t out = task.out;
     bool idle = false;
+    if constexpr (TWO) out_scale = __uint_as_float((254u - ctl[1 + task.ld_stage[(KIND == 1 && wave >= 4) ? 2 : 0]]) << 23);
     if constexpr (KIND == 0) {
         a_tile0 = 4 * (wave >> 2); b_tile0 = 2 * (wave & 3); row0 = 32 * a_tile0; col0 = 32 * b_tile0;
     } else if constexpr (KIND == 1) {
@@ -132,6 +172,10 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         gsrc[k] = base + (int64_t)(task.ld_grp[k] + (rgi < task.ld_n[k] ? rgi : 0)) * GROUP_FLOATS + pt * 4;
     }
     const int wr_off = pt * Im::PS + 8 * swz(rgi, pt);             // + piece * PL + 256 k
+    if constexpr (TWO && KIND == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) up_row[e] = __uint_as_float(ctl[1 + task.ld_stage[0] + (rgi < 2 ? 4 * rgi + e : 0)] << 23);
+    }
     // ---- fragment reads: in read r (0, 1) lane 4q+p of group g addresses point 8 (g >> 1) + 4 r + q, rows 4p..4p+3 of
     // the half (g & 1) of a 32-row tile; the lane ends up with rows (lane & 31), k-slots 8 (lane >> 5) + 0..7
     int rd[2];
@@ -173,17 +217,44 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         } else {
             v = stage[SET][k];
         }
-        bf16x4 h, m, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __bf16 a, b, c;
-            split3(v[e], a, b, c);
-            h[e] = a; m[e] = b; l[e] = c;
-        }
         char* dst = img + wr_off + 256 * k;
-        *reinterpret_cast<bf16x4*>(dst) = h;
-        *reinterpret_cast<bf16x4*>(dst + Im::PL) = m;
-        *reinterpret_cast<bf16x4*>(dst + 2 * Im::PL) = l;
+        if constexpr (TWO) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 p0, p1;
+            if constexpr (k < NGRAD) {       // dY rows, scaled: hi | unscaled residual | hi * 2^-11
+                uint32_t h0, l0, h1, l1;
+                if constexpr (KIND == 3) {
+                    split2u_pair(v[0] * up_row[0], v[1] * up_row[1], h0, l0);
+                    split2u_pair(v[2] * up_row[2], v[3] * up_row[3], h1, l1);
+                } else {
+                    split2u_pair(v[0] * up[k], v[1] * up[k], h0, l0);
+                    split2u_pair(v[2] * up[k], v[3] * up[k], h1, l1);
+                }
+                p0 = u32x2{h0, h1}; p1 = u32x2{l0, l1};
+                const nerfx2::f16x2 down = {(_Float16)nerfx2::LO_UNSCALE, (_Float16)nerfx2::LO_UNSCALE};
+                const u32x2 p2 = {__builtin_bit_cast(uint32_t, __builtin_bit_cast(nerfx2::f16x2, h0) * down),
+                                  __builtin_bit_cast(uint32_t, __builtin_bit_cast(nerfx2::f16x2, h1) * down)};
+                *reinterpret_cast<u32x2*>(dst + 2 * Im::PL) = p2;
+            } else {                         // activations: hi | scaled residual
+                uint32_t h0, l0, h1, l1;
+                nerfx2::split2_pair(v[0], v[1], h0, l0);
+                nerfx2::split2_pair(v[2], v[3], h1, l1);
+                p0 = u32x2{h0, h1}; p1 = u32x2{l0, l1};
+            }
+            *reinterpret_cast<u32x2*>(dst) = p0;
+            *reinterpret_cast<u32x2*>(dst + Im::PL) = p1;
+        } else {
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 a, b, c;
+                split3(v[e], a, b, c);
+                h[e] = a; m[e] = b; l[e] = c;
+            }
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + Im::PL) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * Im::PL) = l;
+        }
         if constexpr (k < NBIAS) {   // (no branch: the compiler's load bookkeeping stays exact in straight-line code)
             const bool live = chunk < c1;   // (a select, not a product with 0: an infinite dY of a repeated chunk must not turn into NaN)
 #pragma unroll
@@ -215,11 +286,11 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     auto run_stage = [&]<int P, int S>(int64_t c) {
         const char* cur = smem + P * Im::STAGE;
         char* nxt = smem + (P ^ 1) * Im::STAGE;
-        bf16x8 B[TN][3];                                 // the column fragments of this stage, pieces hi, mid, lo
+        bf16x8 B[TN][NPB];                               // the column fragments of this stage, piece by piece
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) B[j][s] = frag(cur + s * Im::PL, off_b + 64 * j);
+            for (int s = 0; s < NPB; ++s) B[j][s] = frag(cur + s * Im::PL, off_b + 64 * j);
         constexpr int ABUF = 2;                          // a row tile's fragments, read one tile ahead
         bf16x8 A[ABUF][3];
         auto read_a = [&]<int i>() {
@@ -233,10 +304,17 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
             __builtin_amdgcn_sched_barrier(0);
             // (idle waves of a head task multiply too: what they read is finite, and they store nothing)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (TWO) {                     // (hi * 2^-11).lo, residual.hi, hi.hi
+                    acc[i][j] = mfma32h(A[i % ABUF][2], B[j][1], acc[i][j]);
+                    acc[i][j] = mfma32h(A[i % ABUF][1], B[j][0], acc[i][j]);
+                    acc[i][j] = mfma32h(A[i % ABUF][0], B[j][0], acc[i][j]);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 6; ++q)              // (dY piece, input piece), smallest products first
-                    acc[i][j] = mfma32(A[i % ABUF][PROD_W[q]], B[j][PROD_X[q]], acc[i][j]);
+                    for (int q = 0; q < 6; ++q)          // (dY piece, input piece), smallest products first
+                        acc[i][j] = mfma32(A[i % ABUF][PROD_W[q]], B[j][PROD_X[q]], acc[i][j]);
+                }
+            }
             // staging of stage c + 1 behind the matrix work: load k is split when row tile group(k) multiplies, and
             // its registers are re-requested for stage c + 3
             static_for<NL>([&]<int k>() {
@@ -286,7 +364,12 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < task.M && col < task.N) o[(int64_t)row * ldc + col] = acc[i][j][r];
+                    if (row < task.M && col < task.N) {
+                        float val = acc[i][j][r];
+                        if constexpr (TWO && KIND == 3) val *= __uint_as_float((254u - ctl[1 + task.ld_stage[0] + row]) << 23);
+                        else if constexpr (TWO) val *= out_scale;
+                        o[(int64_t)row * ldc + col] = val;
+                    }
                 }
             }
     }
@@ -307,9 +390,13 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     }
 }
 
+// ctl (mlp_dw.hpp): the two-piece form runs only while ctl[0] == 0 and reads its scales there; the three-piece form
+// runs always (ctl == nullptr) or only when ctl[0] != 0
+template <bool TWO>
 __global__ void __launch_bounds__(DWX_THREADS, 2)
 k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __restrict__ act, const float* __restrict__ scr,
-        float* __restrict__ slabs, int64_t slab_stride) {
+        float* __restrict__ slabs, int64_t slab_stride, const uint32_t* __restrict__ ctl) {
+    if (TWO ? ctl[0] != 0u : (ctl != nullptr && ctl[0] == 0u)) return;
     extern __shared__ __attribute__((aligned(16))) char smem_dw[];
     int ti = 0;
     for (int i = 1; i < tasks.n; ++i)
@@ -318,10 +405,43 @@ k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __res
     const int split = (int)blockIdx.x - task.first;
     float* slab = slabs + (int64_t)split * slab_stride;
     switch (task.kind) {
-        case 0: dwx_loop<0>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
-        case 1: dwx_loop<1>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
-        case 2: dwx_loop<2>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
-        default: dwx_loop<3>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw); break;
+        case 0: dwx_loop<0, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
+        case 1: dwx_loop<1, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
+        case 2: dwx_loop<2, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
+        default: dwx_loop<3, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
+    }
+}
+
+// Control words of the two-piece form (mlp_dw.hpp) from the per-tile words the two-piece stages before it left behind.
+__global__ void __launch_bounds__(1024) k_dw_scales(int64_t n_tiles, const uint32_t* __restrict__ fwd_flags,
+                                                    const uint32_t* __restrict__ bwd_flags, const uint32_t* __restrict__ tile_max,
+                                                    uint32_t* __restrict__ ctl) {
+    __shared__ uint32_t red[1 + nerfdw::DY_STAGES];
+    if (threadIdx.x <= nerfdw::DY_STAGES) red[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t any = 0u, mx[nerfdw::DY_STAGES];
+#pragma unroll
+    for (int s = 0; s < nerfdw::DY_STAGES; ++s) mx[s] = 0u;
+    for (int64_t t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        any |= bwd_flags[t] | (fwd_flags ? fwd_flags[t] : 0u);
+#pragma unroll
+        for (int s = 0; s < nerfdw::DY_STAGES; ++s) {
+            const uint32_t e = tile_max[t * nerfdw::DY_STAGES + s];
+            mx[s] = e > mx[s] ? e : mx[s];
+        }
+    }
+    if (any) atomicOr(&red[0], 1u);
+#pragma unroll
+    for (int s = 0; s < nerfdw::DY_STAGES; ++s)
+        if (mx[s]) atomicMax(&red[1 + s], mx[s]);
+    __syncthreads();
+    if (threadIdx.x == 0) ctl[0] = red[0];
+    if (threadIdx.x >= 1 && threadIdx.x <= nerfdw::DY_STAGES) {
+        // the group's values are below 2^(e - 127): times 2^(14 + 127 - e) they are below 2^14
+        const int e = (int)red[threadIdx.x];
+        int word = e == 0 ? 127 : 127 + 14 + 127 - e;
+        word = word < 2 ? 2 : (word > 252 ? 252 : word);     // (2^k and 2^-k both normal floats)
+        ctl[threadIdx.x] = (uint32_t)word;
     }
 }
 
@@ -330,29 +450,34 @@ k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __res
 namespace nerfdw {
 
 // dW = dY X^T over all layers in one launch on the split-operand kernel, then the fixed-order sum of the partial slabs.
-int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
-              float* d_params, hipStream_t stream) {
+// ctl == nullptr: three pieces.  Otherwise both forms are launched and the control words decide on the device which
+// of them does the work (the other's workgroups return at once); they write the same slabs.
+static int run_dw_split(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
+                        float* d_params, const uint32_t* ctl, hipStream_t stream) {
     const ParamOffsets po = param_offsets(use_viewdirs, output_ch);
     const int SCR_HEAD = scr_head(use_viewdirs), SCR_HEAD2 = SCR_HEAD + 32;
     DwxTasks tk{};
     int cost[14];
     int nt = 0;
-    auto load = [](DwxTask& t, int k, int src, int row, int rows) { t.ld_src[k] = src; t.ld_grp[k] = row / 4; t.ld_n[k] = rows / 4 > 32 ? 32 : rows / 4; };
-    auto big = [&](int a_row, int b_row, int ldc, int64_t out, int64_t bias) {
+    // (stage: for dY loads, the group of dY rows as mlp_dw.hpp numbers them)
+    auto load = [](DwxTask& t, int k, int src, int row, int rows, int stage = 0) {
+        t.ld_src[k] = src; t.ld_grp[k] = row / 4; t.ld_n[k] = rows / 4 > 32 ? 32 : rows / 4; t.ld_stage[k] = stage;
+    };
+    auto big = [&](int a_row, int b_row, int ldc, int64_t out, int64_t bias, int stage) {
         DwxTask t{};
         t.kind = 0;
-        load(t, 0, 0, a_row, 128); load(t, 1, 0, a_row + 128, 128); load(t, 2, 1, b_row, 128); load(t, 3, 1, b_row + 128, 128);
+        load(t, 0, 0, a_row, 128, stage); load(t, 1, 0, a_row + 128, 128, stage); load(t, 2, 1, b_row, 128); load(t, 3, 1, b_row + 128, 128);
         t.M = 256; t.N = 256; t.ldc = ldc; t.out = out; t.bias = bias;
         cost[nt] = 16; tk.t[nt++] = t;
     };
     for (int l = 1; l < 8; ++l)
-        big(SCR_H0 + 256 * l, ACT_H0 + 256 * (l - 1), (l == 5) ? W + IN_PTS : W, po.pts_w[l] + (l == 5 ? IN_PTS : 0), po.pts_b[l]);
-    if (use_viewdirs) big(SCR_FEAT, ACT_H0 + 256 * 7, W, po.feat_w, po.feat_b);
+        big(SCR_H0 + 256 * l, ACT_H0 + 256 * (l - 1), (l == 5) ? W + IN_PTS : W, po.pts_w[l] + (l == 5 ? IN_PTS : 0), po.pts_b[l], dy_stage_layer(l));
+    if (use_viewdirs) big(SCR_FEAT, ACT_H0 + 256 * 7, W, po.feat_w, po.feat_b, DY_STAGE_FEAT);
     {   // encoded positions feed layers 0 and 5
         DwxTask t{};
         t.kind = 1;
-        load(t, 0, 0, SCR_H0, 128); load(t, 1, 0, SCR_H0 + 128, 128);
-        load(t, 2, 0, SCR_H0 + 256 * 5, 128); load(t, 3, 0, SCR_H0 + 256 * 5 + 128, 128);
+        load(t, 0, 0, SCR_H0, 128, dy_stage_layer(0)); load(t, 1, 0, SCR_H0 + 128, 128, dy_stage_layer(0));
+        load(t, 2, 0, SCR_H0 + 256 * 5, 128, dy_stage_layer(5)); load(t, 3, 0, SCR_H0 + 256 * 5 + 128, 128, dy_stage_layer(5));
         load(t, 4, 1, ACT_ENC_PTS, 64);
         t.M = 256; t.N = IN_PTS; t.ldc = IN_PTS; t.ldc2 = W + IN_PTS; t.out = po.pts_w[0]; t.out2 = po.pts_w[5]; t.bias = po.pts_b[0];
         cost[nt] = 13; tk.t[nt++] = t;
@@ -360,12 +485,12 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
     if (use_viewdirs) {
         DwxTask t{};   // views layer: dY x (feature ++ encoded direction); the weight's 283 columns are contiguous
         t.kind = 2;
-        load(t, 0, 0, SCR_VIEWS, 128); load(t, 1, 1, ACT_FEAT, 128); load(t, 2, 1, ACT_FEAT + 128, 128); load(t, 3, 1, ACT_ENC_DIRS, 32);
+        load(t, 0, 0, SCR_VIEWS, 128, DY_STAGE_VIEWS); load(t, 1, 1, ACT_FEAT, 128); load(t, 2, 1, ACT_FEAT + 128, 128); load(t, 3, 1, ACT_ENC_DIRS, 32);
         t.M = 128; t.N = W + IN_DIRS; t.ldc = po.views_in; t.out = po.views_w; t.bias = po.views_b;
         cost[nt] = 12; tk.t[nt++] = t;
         DwxTask a{};   // alpha: dL/d(sigma) x h7
         a.kind = 3;
-        load(a, 0, 0, SCR_HEAD2, 8); load(a, 1, 1, ACT_H0 + 256 * 7, 128); load(a, 2, 1, ACT_H0 + 256 * 7 + 128, 128);
+        load(a, 0, 0, SCR_HEAD2, 8, 4); load(a, 1, 1, ACT_H0 + 256 * 7, 128); load(a, 2, 1, ACT_H0 + 256 * 7 + 128, 128);   // (density: channel 4)
         a.M = 1; a.N = 256; a.ldc = W; a.out = po.alpha_w; a.bias = po.alpha_b;
         cost[nt] = 6; tk.t[nt++] = a;
         DwxTask c{};   // rgb: dL/d(rgb) x views hidden
@@ -424,13 +549,35 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: memset: %s", hipGetErrorString(e));
     }
     const size_t lds = DWX_LDS_BYTES;
-    e = lds_limit_once(reinterpret_cast<const void*>(k_dw_x3), lds);
+    e = lds_limit_once(reinterpret_cast<const void*>(k_dw_x3<false>), lds);
     if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_dw_x3, dim3(n_wg), dim3(DWX_THREADS), lds, stream, tk, nchunks,
-                       (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab);
+    if (ctl != nullptr) {
+        e = lds_limit_once(reinterpret_cast<const void*>(k_dw_x3<true>), lds);
+        if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_dw_x3<true>, dim3(n_wg), dim3(DWX_THREADS), lds, stream, tk, nchunks,
+                           (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab, ctl);
+        int rc2 = launched("nerf_mlp_bwd (dW, two pieces)");
+        if (rc2) return rc2;
+    }
+    hipLaunchKernelGGL(k_dw_x3<false>, dim3(n_wg), dim3(DWX_THREADS), lds, stream, tk, nchunks,
+                       (int64_t)act_rows(use_viewdirs) * TILE_PTS, act, scratch, slabs, slab, ctl);
     int rc = launched("nerf_mlp_bwd (dW, split operands)");
     if (rc) return rc;
     return reduce_regions(regions, slabs, slab, d_params, stream);
+}
+
+int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
+              float* d_params, hipStream_t stream) {
+    return run_dw_split(ldp, use_viewdirs, output_ch, act, scratch, slabs, slab, d_params, nullptr, stream);
+}
+
+int run_dw_x2(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
+              float* d_params, const uint32_t* fwd_flags, const uint32_t* bwd_flags, const uint32_t* tile_max, uint32_t* ctl,
+              hipStream_t stream) {
+    hipLaunchKernelGGL(k_dw_scales, dim3(1), dim3(1024), 0, stream, ldp / TILE_PTS, fwd_flags, bwd_flags, tile_max, ctl);
+    int rc = launched("nerf_mlp_bwd (dW scales)");
+    if (rc) return rc;
+    return run_dw_split(ldp, use_viewdirs, output_ch, act, scratch, slabs, slab, d_params, ctl, stream);
 }
 
 }  // namespace nerfdw

@@ -620,25 +620,43 @@ def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tens
     return d_flat
 
 
+DY_STAGES, DW_CTL_WORDS = 18, 24     # NERF_DY_STAGES, NERF_DW_CTL_WORDS of include/nerf_hip.h
+
+
 def mlp_backward_f16x2(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x2: torch.Tensor,
                        packed_bwd_x2: torch.Tensor, packed_x3: Optional[torch.Tensor], packed_bwd_x3: Optional[torch.Tensor],
-                       use_viewdirs: bool, output_ch: int, want_flags: bool = False):
+                       use_viewdirs: bool, output_ch: int, want_flags: bool = False, fwd_flags: Optional[torch.Tensor] = None,
+                       dw: str = "f16x2"):
     """Parameter gradients with backward-data on the two-piece fp16 kernel (tiles that leave its range are redone by the
-    three-piece kernel; both three-piece streams None = leave them, for tests), then the weight-gradient stage."""
+    three-piece kernel; both three-piece streams None = leave them, for tests), then the weight-gradient stage: on two
+    pieces as well (dw='f16x2'; fwd_flags: the tile flags of the forward that saved `act` -- any marked tile, forward
+    or backward, and the three-piece weight-gradient kernel takes the batch), or on three (dw='bf16x3')."""
     d_out = _f32c(d_out, "d_out")
     n_pts = d_out.shape[0]
-    scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=d_out.device)
+    dev = d_out.device
+    scratch = torch.empty(lib.nerf_mlp_scratch_floats(int(use_viewdirs), n_pts), dtype=torch.float32, device=dev)
     tile = lib.nerf_mlp_f16x2_tile_points()
-    flags = torch.empty(((n_pts + tile - 1) // tile,), dtype=torch.int32, device=d_out.device)
+    n_tiles = (n_pts + tile - 1) // tile
+    two = dw == "f16x2"
+    # one int32 buffer: tile flags | per-tile maxima | control words
+    words = torch.empty(n_tiles * (1 + (DY_STAGES if two else 0)) + (DW_CTL_WORDS if two else 0), dtype=torch.int32, device=dev)
+    flags = words[:n_tiles]
+    tile_max = words[n_tiles:n_tiles * (1 + DY_STAGES)] if two else None
+    ctl = words[n_tiles * (1 + DY_STAGES):] if two else None
     d_flat = torch.empty_like(flat)
-    with torch.cuda.device(d_out.device):
+    with torch.cuda.device(dev):
         with _timed("mlp_bwd_data", n_pts):
             check(lib.nerf_mlp_bwd_data_f16x2(n_pts, d_out.data_ptr(), act.data_ptr(), int(use_viewdirs), output_ch,
                                               packed_x2.data_ptr(), packed_bwd_x2.data_ptr(), _ptr(packed_x3), _ptr(packed_bwd_x3),
-                                              scratch.data_ptr(), flags.data_ptr(), _stream()))
+                                              scratch.data_ptr(), flags.data_ptr(), _ptr(tile_max), _stream()))
         with _timed("mlp_bwd_dw", n_pts):
-            check(lib.nerf_mlp_bwd_weights_bf16x3(n_pts, act.data_ptr(), int(use_viewdirs), output_ch, scratch.data_ptr(),
-                                                  d_flat.data_ptr(), _stream()))
+            if two:
+                check(lib.nerf_mlp_bwd_weights_f16x2(n_pts, act.data_ptr(), int(use_viewdirs), output_ch, scratch.data_ptr(),
+                                                     d_flat.data_ptr(), _ptr(fwd_flags), flags.data_ptr(), tile_max.data_ptr(),
+                                                     ctl.data_ptr(), _stream()))
+            else:
+                check(lib.nerf_mlp_bwd_weights_bf16x3(n_pts, act.data_ptr(), int(use_viewdirs), output_ch, scratch.data_ptr(),
+                                                      d_flat.data_ptr(), _stream()))
     if MARKED is not None:
         MARKED.append(("backward_data", flags))
     return (d_flat, flags) if want_flags else d_flat
@@ -658,28 +676,30 @@ class _FusedMLP(torch.autograd.Function):
     def forward(ctx, pts, viewdirs, model, pts_per_ray, need_grad, *params):
         kind = train_kernels(model)
         two_piece = kind == "bf16x3" and pts_per_ray > 0 and getattr(model, "mlp_dtype", "f32") != "bf16x3"
-        flat = model._flat()
+        streams = model._train_streams() if (two_piece and need_grad) else None
+        flat = streams[0] if streams is not None else model._flat()
         n_pts = pts.numel() // (3 if pts_per_ray > 0 else pts.shape[-1])
         act = mlp_act_buffer(n_pts, model.use_viewdirs, pts.device) if need_grad else None
         if pts_per_ray == 0:      # pre-encoded rows (NeRF.forward(x)); every backward reads what this forward saves
             out = mlp_forward_encoded(pts, model._packed(), model.use_viewdirs, model.output_ch, act)
         elif two_piece:
             # the two-piece fp16 kernel, saving activations; marked tiles are redone (and re-saved) by the three-piece kernel
-            out = mlp_forward_f16x2(pts, viewdirs, model._packed_f16x2(with_bwd=need_grad), model._packed_bf16x3(with_bwd=need_grad),
-                                    model.use_viewdirs, model.output_ch, pts_per_ray, act)
+            x2f, x3f = (streams[1], streams[3]) if streams is not None else (model._packed_f16x2(), model._packed_bf16x3())
+            out, fwd_flags = mlp_forward_f16x2(pts, viewdirs, x2f, x3f, model.use_viewdirs, model.output_ch, pts_per_ray, act,
+                                               want_flags=True)
         elif kind == "bf16x3":
             out = mlp_forward_bf16x3(pts, viewdirs, model._packed_bf16x3(with_bwd=need_grad), model.use_viewdirs, model.output_ch,
                                      pts_per_ray, act)
         else:
             out = mlp_forward_x4(pts, viewdirs, model._packed_x4(), model.use_viewdirs, model.output_ch, pts_per_ray, act)
         if need_grad:
-            if kind == "bf16x3":
-                fwd, bwd = model._packed_bf16x3(), model._packed_bwd_bf16x3()
-            else:
-                fwd, bwd = model._packed_x4(), model._packed_bwd_x4()
             if two_piece:
-                ctx.save_for_backward(act, fwd, bwd, flat, model._packed_f16x2(with_bwd=True), model._packed_bwd_f16x2())
+                ctx.save_for_backward(act, streams[3], streams[4], flat, streams[1], streams[2], fwd_flags)
             else:
+                if kind == "bf16x3":
+                    fwd, bwd = model._packed_bf16x3(), model._packed_bwd_bf16x3()
+                else:
+                    fwd, bwd = model._packed_x4(), model._packed_bwd_x4()
                 ctx.save_for_backward(act, fwd, bwd, flat)
             ctx.kind = "f16x2" if two_piece else kind
             ctx.model = model
@@ -690,8 +710,9 @@ class _FusedMLP(torch.autograd.Function):
         act, fwd, bwd, flat = ctx.saved_tensors[:4]
         model = ctx.model
         if ctx.kind == "f16x2":
-            x2f, x2b = ctx.saved_tensors[4:]
-            d_flat = mlp_backward_f16x2(d_out, act, flat, x2f, x2b, fwd, bwd, model.use_viewdirs, model.output_ch)
+            x2f, x2b, fwd_flags = ctx.saved_tensors[4:]
+            d_flat = mlp_backward_f16x2(d_out, act, flat, x2f, x2b, fwd, bwd, model.use_viewdirs, model.output_ch,
+                                        fwd_flags=fwd_flags, dw=getattr(model, "dw_dtype", "f16x2"))
         elif ctx.kind == "bf16x3":
             d_flat = mlp_backward_bf16x3(d_out, act, flat, fwd, bwd, model.use_viewdirs, model.output_ch)
         else:

@@ -157,13 +157,19 @@ class NeRF(nn.Module):
         #                    per operand, three piece products per product, fp32 sums; tiles of 128 points whose operands
         #                    leave fp16's normal range are redone on the three-piece kernel.  Training: the same two-piece
         #                    kernel for the forward and its mirror for backward-data (every point's gradient carries a
-        #                    power-of-two scale), weight gradients with operands split exactly into three bf16 pieces, six
-        #                    piece products per product, fp32 sums.  All measure the error of the fp32 instruction against fp64
+        #                    power-of-two scale), weight gradients as dw_dtype below says.  All measure the error of the
+        #                    fp32 instruction against fp64
         #   'bf16x3'         the three-piece kernels everywhere, rendering included
         #   'f32_mfma'       the fp32 matrix instruction, rendering and all of training
         #   'bf16'           no-grad queries only, reduced precision: bf16 operands, fp32 sums, raw outputs within ~1e-2
         #                    of their scale (training with this setting runs the 'f32' kernels)
         self.mlp_dtype = 'f32'
+        # Weight-gradient stage of the default ('f32') training path: 'f16x2' = two fp16 pieces per operand, three matrix
+        # instructions per product into one accumulator, the gradients under one power-of-two scale per layer and batch
+        # (the three-piece kernel takes any batch in which the two-piece forward or backward-data marked a tile);
+        # 'bf16x3' = exact three-way bf16 splits, six instructions.  The first is exact to an fp32 sum's rounding relative
+        # to each weight matrix's largest gradient; the second also relative to every single entry
+        self.dw_dtype = 'f16x2'
 
     # -- kernel plumbing ---------------------------------------------------------------------------
     def fused_arch(self) -> bool:
@@ -272,6 +278,16 @@ class NeRF(nn.Module):
     def _packed_bwd_f16x2(self):
         self._packed_f16x2(with_bwd=True)
         return self._pack16x2b
+
+    def _train_streams(self):
+        """Everything a training step on the default kernels reads, with ONE look at the parameters: (flat parameters,
+        fp16-pair stream, its transposed stream, bf16-triple stream, its transposed stream)."""
+        flat = self._flat()
+        if self._pack16x2 is None or self._pack16x2b is None:
+            self._packed_f16x2(with_bwd=True)
+        if self._pack16x3 is None or self._pack16x3b is None:
+            self._packed_x3_pair()
+        return flat, self._pack16x2, self._pack16x2b, self._pack16x3, self._pack16x3b
 
     def _packed_bwd_bf16x3(self):
         self._flat()

@@ -1,5 +1,6 @@
-"""Backward-data on two fp16 pieces per operand (the default training path's first gradient stage): agreement with the
-three-piece kernel and with fp64, the per-point power-of-two scales, and the range rule with its fall-back."""
+"""Backward-data and the weight-gradient stage on two fp16 pieces per operand (the default training path): agreement
+with the three-piece kernels and with fp64, the power-of-two scales (per point; per layer and batch), and the range rules
+with their fall-backs."""
 import numpy as np
 import pytest
 import torch
@@ -31,9 +32,9 @@ class _Case:
             self.raw = ops.mlp_forward_f16x2(self.flat_pts, self.dirs, self.x2[0], self.x3[0], True, 5, s, self.act)
         self.G = T(rng.normal(size=(n * s, 4)).astype(np.float32)).to(device)
 
-    def two(self, G, fallback=True):
+    def two(self, G, fallback=True, dw="f16x2"):
         x3 = self.x3 if fallback else (None, None)
-        d, flags = self.ops.mlp_backward_f16x2(G, self.act, self.m._flat(), *self.x2, *x3, True, 5, want_flags=True)
+        d, flags = self.ops.mlp_backward_f16x2(G, self.act, self.m._flat(), *self.x2, *x3, True, 5, want_flags=True, dw=dw)
         return d.cpu().numpy(), flags.cpu().numpy()
 
     def three(self, G):
@@ -149,3 +150,92 @@ def test_a_default_model_trains_on_the_two_piece_stage(device):
         (qf(c.pts.to(device), c.dirs, c.m) * G).sum().backward()
         got = torch.cat([p.grad.reshape(-1) for p in c.m.parameters()]).cpu().numpy()
         assert _same(got, want), dtype
+
+
+def test_two_piece_weight_gradients_against_three_pieces_and_fp64(device):
+    """The weight-gradient stage alone (same dY rows, which the two-piece backward-data stage left): per tensor, the
+    two-piece products are as far from an fp64 evaluation as the three-piece ones (1.5x, or 1e-6 of the tensor's largest
+    entry), with gradients whose sizes differ by six orders of magnitude from layer group to layer group (colour and
+    density terms) and from point to point."""
+    sd = _peaky(O.random_state_dict(95), 5.0)
+    c = _Case(device, sd, n=70, s=64)
+    rng = np.random.Generator(np.random.PCG64(9))
+    spread = torch.from_numpy((10.0 ** rng.uniform(-6, 0, size=(c.n * c.s, 1))).astype(np.float32)).to(device)
+    for G in (c.G, c.G * spread, c.G * torch.tensor([1e-6, 1e-6, 1e-6, 1.0], device=device), c.G * torch.tensor([1.0, 1.0, 1.0, 1e-6], device=device)):
+        d2, flags = c.two(G, dw="f16x2")
+        d3, _ = c.two(G, dw="bf16x3")
+        assert flags.sum() == 0
+        params = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        (O.query_field(c.pts.double(), c.vd.double(), params) * G.cpu().double().reshape(70, 64, 4)).sum().backward()
+        off = 0
+        for k, p in c.m.named_parameters():
+            n = p.numel()
+            truth = params[k].grad.reshape(-1).numpy()
+            scale = float(np.abs(truth).max())
+            e2 = np.abs(d2[off:off + n] - truth).max() / scale
+            e3 = np.abs(d3[off:off + n] - truth).max() / scale
+            assert e2 <= max(1.5 * e3, 1e-6), (k, e2, e3)
+            off += n
+
+
+def test_a_marked_tile_sends_the_weight_gradients_to_the_three_piece_kernel(device):
+    """The choice is made on the device: one marked tile, in the backward-data stage (a subnormal upstream gradient) or
+    in the forward that saved the activations (positions far outside), and the result is the three-piece weight-gradient
+    kernel's bit for bit; nothing marked, and it is not (the two forms round differently)."""
+    from test_gpu_parity import _query_fn
+    c = _Case(device, O.random_state_dict(96))
+    G = c.G.clone()
+    G[128:256] *= 1e-42
+    d2, flags = c.two(G, dw="f16x2")
+    d3, _ = c.two(G, dw="bf16x3")
+    assert flags.sum() == 1 and _same(d2, d3)
+    d2, flags = c.two(c.G, dw="f16x2")
+    d3, _ = c.two(c.G, dw="bf16x3")
+    assert flags.sum() == 0 and not _same(d2, d3)
+    # through a model's autograd: the forward's flags reach the weight-gradient stage
+    qf = _query_fn()
+    far = c.pts.clone()
+    far.reshape(-1, 3)[2 * 128: 3 * 128] *= 1e5
+    grads = {}
+    for dw in ("f16x2", "bf16x3"):
+        c.m.dw_dtype = dw
+        c.m.zero_grad()
+        (qf(far.to(device), c.dirs, c.m) * c.G.reshape(c.n, c.s, 4)).sum().backward()
+        grads[dw] = torch.cat([p.grad.reshape(-1) for p in c.m.parameters()]).cpu().numpy()
+    assert _same(grads["f16x2"], grads["bf16x3"])
+
+
+def test_what_the_two_piece_weight_gradients_keep_of_small_rows_and_columns(device):
+    """Activations keep 22 bits of their own magnitude: the weights behind an input unit that stays around 1e-5 for the
+    whole batch (layer 3's unit 7, through its weights and bias) get gradients as accurate, relative to that column, as
+    from three pieces.  The gradient side is exact to 2^-39 of its layer's largest gradient in the batch: a unit whose
+    gradients stay 1e-7 of that (layer 4's unit 9, through the weights that read it) keeps its row of the weight
+    gradient to 1e-3 of the row's largest entry; every tensor as a whole stays within 1e-6 of its largest entry."""
+    sd = O.random_state_dict(97)
+    sd["pts_linears.3.weight"][7] *= 1e-5
+    sd["pts_linears.3.bias"][7] = 1e-5
+    sd["pts_linears.5.weight"][:, 63 + 9] *= 1e-7          # (layer 5 reads [encoding, h4])
+    c = _Case(device, sd, n=70, s=64)
+    d2, flags = c.two(c.G, dw="f16x2")
+    d3, _ = c.two(c.G, dw="bf16x3")
+    assert flags.sum() == 0
+    params = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    (O.query_field(c.pts.double(), c.vd.double(), params) * c.G.cpu().double().reshape(70, 64, 4)).sum().backward()
+    off = 0
+    for k, p in c.m.named_parameters():
+        n = p.numel()
+        if k == "pts_linears.4.weight":
+            truth = params[k].grad.numpy()
+            g2, g3 = d2[off:off + n].reshape(truth.shape), d3[off:off + n].reshape(truth.shape)
+            whole = np.abs(truth).max()
+            col = np.abs(truth[:, 7]).max()
+            assert col < 1e-3 * whole
+            assert np.abs(g3[:, 7] - truth[:, 7]).max() <= 1e-5 * col
+            assert np.abs(g2[:, 7] - truth[:, 7]).max() <= 1e-5 * col
+            # (the row's dY comes out of the two-piece backward-data stage, whose weights are exact to 2^-36 absolute: for
+            # weights of 1e-8 that is its own loss; here the weight-gradient stages are compared on the SAME dY rows)
+            row = np.abs(g3[9]).max()
+            assert 0 < row < 1e-5 * whole
+            assert np.abs(g2[9] - g3[9]).max() <= 1e-3 * row
+            assert np.abs(g2 - truth).max() <= 1e-6 * whole
+        off += n

@@ -28,6 +28,7 @@ with torch.no_grad():
 G = torch.randn(n, 4, device=dev) * 1e-4
 scratch = torch.empty(lib.nerf_mlp_scratch_floats(1, n), dtype=torch.float32, device=dev)
 flags = torch.zeros((n + 127) // 128, dtype=torch.int32, device=dev)
+tile_max = torch.zeros(((n + 127) // 128, 18), dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 
 
@@ -37,7 +38,7 @@ def run():
     else:
         fb = (x3[0].data_ptr(), x3[1].data_ptr()) if which == "x2" else (None, None)
         check(lib.nerf_mlp_bwd_data_f16x2(n, G.data_ptr(), act.data_ptr(), 1, 5, x2[0].data_ptr(), x2[1].data_ptr(), fb[0], fb[1],
-                                          scratch.data_ptr(), flags.data_ptr(), st))
+                                          scratch.data_ptr(), flags.data_ptr(), tile_max.data_ptr() if os.environ.get("NO_TILE_MAX") is None else None, st))
 
 
 for _ in range(3):

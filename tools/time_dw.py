@@ -1,4 +1,4 @@
-"""Times the weight-gradient stage alone on random operands: python3 tools/time_dw.py [n_pts] [reps]
+"""Times the weight-gradient stage alone on random operands: python3 tools/time_dw.py [n_pts] [reps] [x3|x2]
 (NERF_HIP_LIB selects a variant build of the library).  Prints ms per call and algorithmic TFLOP/s / TB/s."""
 import os
 import sys
@@ -10,6 +10,7 @@ from nerf_amd._lib import check, lib  # noqa: E402
 
 n_pts = int(sys.argv[1]) if len(sys.argv) > 1 else 8192 * 192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+which = sys.argv[3] if len(sys.argv) > 3 else "x3"
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 g = torch.Generator(device=dev).manual_seed(0)
@@ -20,8 +21,18 @@ d_params = torch.empty(lib.nerf_mlp_n_params(1, 5), device=dev)
 s = torch.cuda.current_stream().cuda_stream
 
 
+n_tiles = (n_pts + 127) // 128
+flags = torch.zeros(n_tiles, dtype=torch.int32, device=dev)
+tile_max = torch.full((n_tiles, 18), 127 + 3 + 1, dtype=torch.int32, device=dev)      # every group: magnitudes below 2^3
+ctl = torch.zeros(24, dtype=torch.int32, device=dev)
+
+
 def call():
-    check(lib.nerf_mlp_bwd_weights_bf16x3(n_pts, act.data_ptr(), 1, 5, scr.data_ptr(), d_params.data_ptr(), s))
+    if which == "x2":
+        check(lib.nerf_mlp_bwd_weights_f16x2(n_pts, act.data_ptr(), 1, 5, scr.data_ptr(), d_params.data_ptr(), None, flags.data_ptr(),
+                                             tile_max.data_ptr(), ctl.data_ptr(), s))
+    else:
+        check(lib.nerf_mlp_bwd_weights_bf16x3(n_pts, act.data_ptr(), 1, 5, scr.data_ptr(), d_params.data_ptr(), s))
 
 
 for _ in range(3):
@@ -35,5 +46,5 @@ ev[1].record()
 torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / reps
 nbytes = n_pts * 4 * (2528 + 2432 + 12)
-print(f"{os.environ.get('NERF_HIP_LIB', 'product'):40s} n_pts {n_pts}: {ms:.3f} ms  {n_pts * 1186816 / ms / 1e9:.1f} TFLOP/s alg  "
+print(f"{which} {os.environ.get('NERF_HIP_LIB', 'product'):40s} n_pts {n_pts}: {ms:.3f} ms  {n_pts * 1186816 / ms / 1e9:.1f} TFLOP/s alg  "
       f"{nbytes / ms / 1e9:.2f} TB/s  checksum {float(d_params.double().abs().sum()):.6e}")
