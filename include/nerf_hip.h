@@ -299,7 +299,7 @@ int nerf_mlp_bwd_weights_bf16x3(int64_t n_pts, const float* act, int use_viewdir
  * rows, the largest magnitude stored, as exponent bits + 1 (0 = all zeros) -- what nerf_mlp_bwd_weights_f16x2 takes its
  * scales from.  The weight-gradient stage that follows is nerf_mlp_bwd_weights_f16x2 or nerf_mlp_bwd_weights_bf16x3. */
 #define NERF_DY_STAGES 18
-#define NERF_DW_CTL_WORDS 24
+#define NERF_DW_CTL_WORDS 4096
 int64_t nerf_mlp_packed_bwd_f16x2_bytes(int use_viewdirs);
 int nerf_pack_weights_bwd_f16x2(int use_viewdirs, int output_ch, const float* params, void* packed_bwd_f16x2, void* stream);
 int nerf_mlp_bwd_data_f16x2(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,

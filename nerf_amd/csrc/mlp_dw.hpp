@@ -39,11 +39,12 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
 // magnitude it stored for each group of dY rows as exponent bits + 1 (0 = nothing but zeros).  Stages 0..7: the head
 // rows, one per channel of dL/d(raw) (view branch: 0..2 colour, 4 density); 8: view layer; 9: feature layer; 17 - l:
 // pts layer l.  One small kernel turns them, and the tile
-// flags of both two-piece stages, into DW_CTL_WORDS control words: [0] = 1 if any tile was marked (the two-piece
-// weight-gradient kernel then leaves the whole batch to the three-piece one), [1 + stage] = the power of two that
-// takes the stage's largest magnitude to 2^14 (as a biased exponent: the float 2^k has the bits word << 23).
+// flags of both two-piece stages, into DW_CTL_PARTS partial results of DW_CTL_STRIDE words each (DW_CTL_WORDS of
+// workspace), which every weight-gradient workgroup reduces to: any tile marked (the two-piece kernel then leaves the
+// whole batch to the three-piece one), and per stage the power of two that takes its largest magnitude below 2^14.
 constexpr int DY_STAGES = 18;
-constexpr int DW_CTL_WORDS = 24;
+constexpr int DW_CTL_PARTS = 128, DW_CTL_STRIDE = 32;
+constexpr int DW_CTL_WORDS = DW_CTL_PARTS * DW_CTL_STRIDE;
 constexpr int DY_STAGE_VIEWS = 8, DY_STAGE_FEAT = 9;
 constexpr int dy_stage_layer(int l) { return 17 - l; }
 int run_dw_x2(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,

@@ -390,13 +390,38 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
     }
 }
 
-// ctl (mlp_dw.hpp): the two-piece form runs only while ctl[0] == 0 and reads its scales there; the three-piece form
-// runs always (ctl == nullptr) or only when ctl[0] != 0
+// Second half, at the start of a weight-gradient workgroup: out[0] = any tile marked; out[1 + s] = the power of two
+// that takes stage s's largest magnitude below 2^14, as a biased exponent (the float 2^k has the bits word << 23).
+__device__ __forceinline__ void control_words(const uint32_t* __restrict__ ctl, uint32_t* out) {
+    const int t = threadIdx.x;
+    if (t <= nerfdw::DY_STAGES) {
+        uint32_t m = 0u;
+        for (int b = 0; b < nerfdw::DW_CTL_PARTS; ++b) {
+            const uint32_t v = ctl[b * nerfdw::DW_CTL_STRIDE + t];
+            m = v > m ? v : m;
+        }
+        if (t > 0) {
+            // the group's values are below 2^(e - 127): times 2^(14 + 127 - e) they are below 2^14
+            int word = m == 0u ? 127 : 127 + 14 + 127 - (int)m;
+            word = word < 2 ? 2 : (word > 252 ? 252 : word);     // (2^k and 2^-k both normal floats)
+            m = (uint32_t)word;
+        }
+        out[t] = m;
+    }
+    __syncthreads();
+}
+
+// ctl (mlp_dw.hpp): the two-piece form runs only while no tile is marked and takes its scales from there; the
+// three-piece form runs always (ctl == nullptr) or only when a tile is marked
 template <bool TWO>
 __global__ void __launch_bounds__(DWX_THREADS, 2)
 k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __restrict__ act, const float* __restrict__ scr,
         float* __restrict__ slabs, int64_t slab_stride, const uint32_t* __restrict__ ctl) {
-    if (TWO ? ctl[0] != 0u : (ctl != nullptr && ctl[0] == 0u)) return;
+    __shared__ uint32_t ctl_s[nerfdw::DY_STAGES + 1];
+    if (TWO || ctl != nullptr) {
+        control_words(ctl, ctl_s);
+        if (TWO ? ctl_s[0] != 0u : ctl_s[0] == 0u) return;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem_dw[];
     int ti = 0;
     for (int i = 1; i < tasks.n; ++i)
@@ -405,24 +430,24 @@ k_dw_x3(DwxTasks tasks, int64_t nchunks, int64_t tile_floats, const float* __res
     const int split = (int)blockIdx.x - task.first;
     float* slab = slabs + (int64_t)split * slab_stride;
     switch (task.kind) {
-        case 0: dwx_loop<0, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
-        case 1: dwx_loop<1, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
-        case 2: dwx_loop<2, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
-        default: dwx_loop<3, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl); break;
+        case 0: dwx_loop<0, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl_s); break;
+        case 1: dwx_loop<1, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl_s); break;
+        case 2: dwx_loop<2, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl_s); break;
+        default: dwx_loop<3, TWO>(task, split, nchunks, tile_floats, act, scr, slab, smem_dw, ctl_s); break;
     }
 }
 
-// Control words of the two-piece form (mlp_dw.hpp) from the per-tile words the two-piece stages before it left behind.
-__global__ void __launch_bounds__(1024) k_dw_scales(int64_t n_tiles, const uint32_t* __restrict__ fwd_flags,
-                                                    const uint32_t* __restrict__ bwd_flags, const uint32_t* __restrict__ tile_max,
-                                                    uint32_t* __restrict__ ctl) {
-    __shared__ uint32_t red[1 + nerfdw::DY_STAGES];
-    if (threadIdx.x <= nerfdw::DY_STAGES) red[threadIdx.x] = 0u;
-    __syncthreads();
+// First half of the control words of the two-piece form (mlp_dw.hpp): DW_CTL_PARTS partial results, one per one-wave
+// workgroup, over the per-tile words the two-piece stages left behind -- word 0: any tile marked; word 1 + s: the
+// largest exponent word of stage s.  (The weight-gradient workgroups finish the reduction themselves, control_words()
+// below: one workgroup scanning all tiles took 40-57 us.)
+__global__ void __launch_bounds__(64) k_dw_scales(int64_t n_tiles, const uint32_t* __restrict__ fwd_flags,
+                                                   const uint32_t* __restrict__ bwd_flags, const uint32_t* __restrict__ tile_max,
+                                                   uint32_t* __restrict__ ctl) {
     uint32_t any = 0u, mx[nerfdw::DY_STAGES];
 #pragma unroll
     for (int s = 0; s < nerfdw::DY_STAGES; ++s) mx[s] = 0u;
-    for (int64_t t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    for (int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x; t < n_tiles; t += (int64_t)gridDim.x * 64) {
         any |= bwd_flags[t] | (fwd_flags ? fwd_flags[t] : 0u);
 #pragma unroll
         for (int s = 0; s < nerfdw::DY_STAGES; ++s) {
@@ -430,18 +455,22 @@ __global__ void __launch_bounds__(1024) k_dw_scales(int64_t n_tiles, const uint3
             mx[s] = e > mx[s] ? e : mx[s];
         }
     }
-    if (any) atomicOr(&red[0], 1u);
+    auto wave_max = [](uint32_t e) -> uint32_t {            // e < 512; bisection over ballots
+        uint32_t best = 0u;
 #pragma unroll
-    for (int s = 0; s < nerfdw::DY_STAGES; ++s)
-        if (mx[s]) atomicMax(&red[1 + s], mx[s]);
-    __syncthreads();
-    if (threadIdx.x == 0) ctl[0] = red[0];
-    if (threadIdx.x >= 1 && threadIdx.x <= nerfdw::DY_STAGES) {
-        // the group's values are below 2^(e - 127): times 2^(14 + 127 - e) they are below 2^14
-        const int e = (int)red[threadIdx.x];
-        int word = e == 0 ? 127 : 127 + 14 + 127 - e;
-        word = word < 2 ? 2 : (word > 252 ? 252 : word);     // (2^k and 2^-k both normal floats)
-        ctl[threadIdx.x] = (uint32_t)word;
+        for (int bit = 8; bit >= 0; --bit) {
+            const uint32_t cand = best | (1u << bit);
+            if (__ballot(e >= cand) != 0ull) best = cand;
+        }
+        return best;
+    };
+    uint32_t* mine = ctl + (int64_t)blockIdx.x * nerfdw::DW_CTL_STRIDE;
+    const uint32_t flag = __ballot(any != 0u) != 0ull ? 1u : 0u;
+    if (threadIdx.x == 0) mine[0] = flag;
+#pragma unroll
+    for (int s = 0; s < nerfdw::DY_STAGES; ++s) {
+        const uint32_t m = wave_max(mx[s] > 511u ? 511u : mx[s]);
+        if (threadIdx.x == 0) mine[1 + s] = m;
     }
 }
 
@@ -574,7 +603,7 @@ int run_dw_x3(int64_t ldp, int use_viewdirs, int output_ch, const float* act, fl
 int run_dw_x2(int64_t ldp, int use_viewdirs, int output_ch, const float* act, float* scratch, float* slabs, int64_t slab,
               float* d_params, const uint32_t* fwd_flags, const uint32_t* bwd_flags, const uint32_t* tile_max, uint32_t* ctl,
               hipStream_t stream) {
-    hipLaunchKernelGGL(k_dw_scales, dim3(1), dim3(1024), 0, stream, ldp / TILE_PTS, fwd_flags, bwd_flags, tile_max, ctl);
+    hipLaunchKernelGGL(k_dw_scales, dim3(DW_CTL_PARTS), dim3(64), 0, stream, ldp / TILE_PTS, fwd_flags, bwd_flags, tile_max, ctl);
     int rc = launched("nerf_mlp_bwd (dW scales)");
     if (rc) return rc;
     return run_dw_split(ldp, use_viewdirs, output_ch, act, scratch, slabs, slab, d_params, ctl, stream);

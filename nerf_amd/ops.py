@@ -620,7 +620,7 @@ def mlp_backward_bf16x3(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tens
     return d_flat
 
 
-DY_STAGES, DW_CTL_WORDS = 18, 24     # NERF_DY_STAGES, NERF_DW_CTL_WORDS of include/nerf_hip.h
+DY_STAGES, DW_CTL_WORDS = 18, 4096     # NERF_DY_STAGES, NERF_DW_CTL_WORDS of include/nerf_hip.h
 
 
 def mlp_backward_f16x2(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tensor, packed_x2: torch.Tensor,

@@ -24,7 +24,7 @@ s = torch.cuda.current_stream().cuda_stream
 n_tiles = (n_pts + 127) // 128
 flags = torch.zeros(n_tiles, dtype=torch.int32, device=dev)
 tile_max = torch.full((n_tiles, 18), 127 + 3 + 1, dtype=torch.int32, device=dev)      # every group: magnitudes below 2^3
-ctl = torch.zeros(24, dtype=torch.int32, device=dev)
+ctl = torch.zeros(4096, dtype=torch.int32, device=dev)
 
 
 def call():
