@@ -138,10 +138,10 @@ int nerf_composite_bwd(int64_t n, int S, const float* raw, const float* z, const
 /* The network is NeRF(D=8, W=256, skips=[4]) (run_nerf_helpers.py:73-133) with L=10 / L=4
  * encodings fused in (run_nerf.py:40-66).  Weights are consumed from packed streams built from the flat concatenation
  * of the module's parameters in state_dict order.  One forward and one backward per arithmetic:
- *   two fp16 pieces per operand on the fp16 matrix instruction (fp32-accurate, the default of the no-grad render):
- *                                                                                nerf_mlp_fwd_f16x2
- *   three bf16 pieces per operand on the bf16 matrix instruction (fp32-accurate, the default of training):
- *                                                                                nerf_mlp_fwd_bf16x3 / nerf_mlp_bwd_bf16x3
+ *   two fp16 pieces per operand on the fp16 matrix instruction (fp32-accurate, the default of rendering and training):
+ *                                              nerf_mlp_fwd_f16x2 / nerf_mlp_bwd_data_f16x2 + nerf_mlp_bwd_weights_f16x2
+ *   three bf16 pieces per operand on the bf16 matrix instruction (fp32-accurate whatever the magnitudes: the fall-back
+ *   of the two-piece kernels):                                                   nerf_mlp_fwd_bf16x3 / nerf_mlp_bwd_bf16x3
  *   the fp32 matrix instruction:                                                 nerf_mlp_fwd_x4     / nerf_mlp_bwd_x4
  *   bf16 operands, fp32 sums (inference only, reduced precision):                nerf_mlp_fwd_bf16
  *   already-encoded inputs, as NeRF.forward(x) receives them upstream:           nerf_mlp_fwd_encoded */
@@ -193,7 +193,7 @@ int nerf_mlp_fwd_bf16(int64_t n_pts, int pts_per_ray, const float* pts, const fl
                       int use_viewdirs, int output_ch, const void* packed_bf16, float* out, void* stream);
 
 /* fp32-accurate variant of nerf_mlp_fwd_x4 on the bf16 matrix instruction (same arguments and outputs; the default
- * of the render path and of training): every fp32 operand of magnitude below 3.39e38 (the largest bf16) is split exactly
+ * of earlier versions, now what nerf_mlp_fwd_f16x2 hands its marked tiles to): every fp32 operand of magnitude below 3.39e38 (the largest bf16) is split exactly
  * into three bf16 pieces and each product is rebuilt from its six largest
  * piece products in fp32 accumulators, which measures the same error against fp64 as the fp32 matrix instruction
  * (NeRF.forward, run_nerf_helpers.py:109-133, behind run_nerf.py:40-66).  Non-finite values: an infinite or NaN operand
@@ -248,7 +248,7 @@ int nerf_pack_weights_bwd_x4(int use_viewdirs, int output_ch, const float* param
 int nerf_mlp_bwd_x4(int64_t n_pts, const float* d_out, const float* act, int use_viewdirs, int output_ch,
                     const float* packed_x4, const float* packed_bwd_x4, float* scratch, float* d_params, void* stream);
 
-/* The same backward on the split-operand scheme, the default (the mirror of nerf_mlp_fwd_bf16x3: dY tiles split
+/* The same backward on three-way bf16 splits (the mirror of nerf_mlp_fwd_bf16x3: dY tiles split
  * exactly into three bf16 pieces, W^T as split triples, six piece products, fp32 sums, in both stages).  Same d_out /
  * act / scratch / d_params as nerf_mlp_bwd_x4.  packed_bf16x3: the
  * stream of nerf_pack_weights_bf16x3 (its fp32 tables are read); packed_bwd_bf16x3: nerf_mlp_packed_bwd_bf16x3_bytes()

@@ -665,7 +665,7 @@ def mlp_backward_f16x2(d_out: torch.Tensor, act: torch.Tensor, flat: torch.Tenso
 def train_kernels(model) -> str:
     """Which kernels a training step of `model` runs: 'mfma32' (forward, backward-data and weight gradients on the fp32
     matrix instruction) for mlp_dtype 'f32_mfma', else 'bf16x3' (all three on split operands: forward and backward-data
-    on two fp16 pieces with the three-piece fall-back, unless mlp_dtype is 'bf16x3'; weight gradients on three bf16 pieces)."""
+    on two fp16 pieces with the three-piece fall-back, unless mlp_dtype is 'bf16x3'; weight gradients as model.dw_dtype says)."""
     return "mfma32" if getattr(model, "mlp_dtype", "f32") == "f32_mfma" else "bf16x3"
 
 
