@@ -221,7 +221,7 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         if constexpr (TWO) {
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             u32x2 p0, p1;
-            if constexpr (k < NGRAD) {       // dY rows, scaled: hi | unscaled residual | hi * 2^-11
+            if constexpr (k < NGRAD) {       // dY rows, scaled: hi | unscaled residual (hi * 2^-11 is made from hi after the read)
                 uint32_t h0, l0, h1, l1;
                 if constexpr (KIND == 3) {
                     split2u_pair(v[0] * up_row[0], v[1] * up_row[1], h0, l0);
@@ -231,10 +231,6 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
                     split2u_pair(v[2] * up[k], v[3] * up[k], h1, l1);
                 }
                 p0 = u32x2{h0, h1}; p1 = u32x2{l0, l1};
-                const nerfx2::f16x2 down = {(_Float16)nerfx2::LO_UNSCALE, (_Float16)nerfx2::LO_UNSCALE};
-                const u32x2 p2 = {__builtin_bit_cast(uint32_t, __builtin_bit_cast(nerfx2::f16x2, h0) * down),
-                                  __builtin_bit_cast(uint32_t, __builtin_bit_cast(nerfx2::f16x2, h1) * down)};
-                *reinterpret_cast<u32x2*>(dst + 2 * Im::PL) = p2;
             } else {                         // activations: hi | scaled residual
                 uint32_t h0, l0, h1, l1;
                 nerfx2::split2_pair(v[0], v[1], h0, l0);
@@ -295,13 +291,22 @@ __device__ __forceinline__ void dwx_loop(const DwxTask& task, int split, int64_t
         bf16x8 A[ABUF][3];
         auto read_a = [&]<int i>() {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) A[i % ABUF][s] = frag(cur + s * Im::PL, off_a + 64 * i);
+            for (int s = 0; s < (TWO ? 2 : 3); ++s) A[i % ABUF][s] = frag(cur + s * Im::PL, off_a + 64 * i);
+        };
+        // two pieces: the third gradient-side fragment is the leading one times 2^-11 (four packed multiplications
+        // instead of an LDS plane written and read)
+        auto third = [&]<int i>() {
+            if constexpr (TWO) {
+                const nerfx2::f16x8 h = __builtin_bit_cast(nerfx2::f16x8, A[i % ABUF][0]);
+                A[i % ABUF][2] = __builtin_bit_cast(bf16x8, h * (_Float16)nerfx2::LO_UNSCALE);
+            }
         };
         if constexpr (ABUF == 2) read_a.template operator()<0>();
         static_for<TM>([&]<int i>() {
             if constexpr (ABUF == 1) read_a.template operator()<i>();
             else if constexpr (i + 1 < TM) read_a.template operator()<i + 1>();
             __builtin_amdgcn_sched_barrier(0);
+            third.template operator()<i>();
             // (idle waves of a head task multiply too: what they read is finite, and they store nothing)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
