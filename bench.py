@@ -796,15 +796,29 @@ def main():
             extra(key, lambda poses_, key=key, kw=kw, c=chunk_rays, n=n_timed: sharded(key, kw, c, n, poses_),
                   prepare=sharded_inputs, collective=True)
 
+    def again_if_launch_bound(run):
+        """A single-GPU eager train leg whose launching thread fell behind the GPU (a host whose cores are busy elsewhere:
+        gpu_busy_share_of_step below 0.85) is timed once more; the faster attempt is the leg's figure and carries the
+        other beside it."""
+        first = run()
+        if world > 1 or first.get("gpu_busy_share_of_step", 1.0) >= 0.85:
+            return first
+        second = run()
+        keep, other = (second, first) if second.get("rays_per_s", 0) >= first.get("rays_per_s", 0) else (first, second)
+        keep["other_attempt"] = {k: other.get(k) for k in ("rays_per_s", "ms_per_step", "gpu_busy_share_of_step")}
+        keep["other_attempt"]["why"] = "the first attempt was launch-bound (gpu_busy_share_of_step < 0.85), so the leg was timed twice"
+        return keep
+
     if not args.no_train:
         ready = legs.ready if world > 1 else None
         # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)
         for key, n_rand, k, w, seed in (("train_8192", 8192, 10, 2, 4321), ("train", 1024, 20, 5, 1234)):
-            extra(key, lambda key=key, n_rand=n_rand, k=k, w=w, seed=seed: time_train(
+            extra(key, lambda key=key, n_rand=n_rand, k=k, w=w, seed=seed: again_if_launch_bound(lambda: time_train(
                 models, kwargs, dev, world, n_rand, k, w, seed=seed + rank, ready=ready, card=card,
-                hook=lambda key=key: injected_failure(key)), collective=True)
+                hook=lambda key=key: injected_failure(key))), collective=True)
         if world == 1:   # configs[2]: fern-shaped step (NDC, density noise, 64 + 64 samples), single-GPU extra
-            extra("train_fern", lambda: time_train(models, kwargs, dev, world, 1024, 10, 3, seed=99, scene="fern", card=card))
+            extra("train_fern", lambda: again_if_launch_bound(
+                lambda: time_train(models, kwargs, dev, world, 1024, 10, 3, seed=99, scene="fern", card=card)))
         if world == 1:   # single-GPU extra; the multi-rank runs keep to the eager step
             extra("train_graphed", lambda: time_train(models, kwargs, dev, world, 1024, 10, 5, seed=1234 + rank, graphed=True, card=card))
 
