@@ -239,3 +239,47 @@ def test_what_the_two_piece_weight_gradients_keep_of_small_rows_and_columns(devi
             assert np.abs(g2[9] - g3[9]).max() <= 1e-3 * row
             assert np.abs(g2 - truth).max() <= 1e-6 * whole
         off += n
+
+
+def test_two_piece_gradient_stages_on_ragged_batches_and_every_head_width(device):
+    """Many small batches of odd sizes (1 .. 700 points: partial tiles, slices of the point range shorter than a stage
+    pair), with and without the view branch, every output width 1..8 of the output_linear head, upstream gradients of
+    random overall size: from the SAME saved activations (two forwards would differ by ReLU units that sit on zero),
+    the parameter gradients of the two-piece stages agree with those of the three-piece stages per tensor to 5e-6 of
+    the tensor's largest entry, nothing is marked, and parameters no stage touches get exact zeros."""
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import NeRF
+    rng = np.random.Generator(np.random.PCG64(31))
+    cases = [(True, 5, 1, 1), (True, 5, 3, 43), (True, 5, 7, 100), (True, 5, 129, 1), (True, 5, 11, 64)]
+    cases += [(False, och, int(rng.integers(1, 40)), int(rng.integers(1, 18))) for och in range(1, 9)]
+    for use_vd, och, n, s in cases:
+        if use_vd:
+            m = _model(O.random_state_dict(500 + n), device)
+        else:
+            m = NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=och, skips=[4], use_viewdirs=False)
+            torch.manual_seed(600 + och)
+            for p in m.parameters():
+                torch.nn.init.uniform_(p, -0.08, 0.08)
+            m = m.to(device)
+        pts, vd = _inputs(rng, n, s, span=2.5)
+        flat_pts, dirs = pts.reshape(-1, 3).to(device), (vd.to(device) if use_vd else None)
+        G = T(rng.normal(size=(n * s, 4 if use_vd else och)).astype(np.float32)).to(device) * float(10.0 ** rng.uniform(-8, 3))
+        act = ops.mlp_act_buffer(n * s, use_vd, device)
+        x3 = (m._packed_bf16x3(with_bwd=True), m._packed_bwd_bf16x3())
+        x2 = (m._packed_f16x2(with_bwd=True), m._packed_bwd_f16x2())
+        with torch.no_grad():
+            _, fwd_flags = ops.mlp_forward_f16x2(flat_pts, dirs, x2[0], x3[0], use_vd, och, s, act, want_flags=True)
+        g2, flags = ops.mlp_backward_f16x2(G, act, m._flat(), *x2, *x3, use_vd, och, want_flags=True, fwd_flags=fwd_flags)
+        g3 = ops.mlp_backward_bf16x3(G, act, m._flat(), *x3, use_vd, och)
+        assert int(fwd_flags.sum()) == 0 and int(flags.sum()) == 0, (use_vd, och, n, s)
+        g2, g3 = g2.cpu().numpy(), g3.cpu().numpy()
+        off = 0
+        for k, p in m.named_parameters():
+            nn = p.numel()
+            a, b = g2[off:off + nn], g3[off:off + nn]
+            off += nn
+            scale = float(np.abs(b).max())
+            if scale == 0.0:
+                assert not a.any(), (use_vd, och, n, s, k)
+            else:
+                assert np.abs(a - b).max() <= 5e-6 * scale, (use_vd, och, n, s, k, np.abs(a - b).max() / scale)
