@@ -101,12 +101,11 @@ __device__ __forceinline__ void layer_x3b(Stream3& st, int lane, int g, const ch
     static_for<NPIECE>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
 }
 
+// one 128-point tile (tile_index) by one workgroup
 template <bool VIEWDIRS>
-__global__ void __launch_bounds__(X3_THREADS, 1)
-k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_out, const float* __restrict__ act,
-                      const char* __restrict__ packed_x3, const char* __restrict__ packed_bwd, float* __restrict__ scr,
-                      const uint32_t* __restrict__ marked) {
-    if (marked != nullptr && marked[blockIdx.x] == 0u) return;   // (second launch behind the two-piece kernel: marked tiles only)
+__device__ __forceinline__ void bwd_tile_x3(int64_t tile_index, int64_t n_pts, int output_ch, const float* __restrict__ d_out,
+                                            const float* __restrict__ act, const char* __restrict__ packed_x3,
+                                            const char* __restrict__ packed_bwd, float* __restrict__ scr) {
     extern __shared__ __attribute__((aligned(16))) char smem3b[];
     char* ring = smem3b;
     float* aux = reinterpret_cast<float*>(smem3b + RING3_BYTES);
@@ -117,8 +116,8 @@ k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_
         for (int i = tid * 4; i < AUX16_FLOATS; i += X3_THREADS * 4)
             *reinterpret_cast<f32x4*>(aux + i) = *reinterpret_cast<const f32x4*>(gaux + i);
     }
-    const float* const at = act + (int64_t)blockIdx.x * act_rows(UV) * TILE_PTS;
-    float* const st_ = scr + (int64_t)blockIdx.x * scr_rows(UV) * TILE_PTS;
+    const float* const at = act + tile_index * act_rows(UV) * TILE_PTS;
+    float* const st_ = scr + tile_index * scr_rows(UV) * TILE_PTS;
     int pw[NCT];
     bool valid[NCT];
     int64_t p[NCT];
@@ -126,7 +125,7 @@ k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         pw[ct] = wave * WAVE_PTS + ct * 16 + (lane & 15);      // point inside the 128-point tile
-        p[ct] = (int64_t)blockIdx.x * TILE_PTS + pw[ct];
+        p[ct] = tile_index * TILE_PTS + pw[ct];
         valid[ct] = p[ct] < n_pts;
         lane_rows[ct] = st_ + g * GROUP_FLOATS + pw[ct] * 4;
     }
@@ -260,6 +259,38 @@ k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_
     layer_x3b<16, 8, true, false, false>(st, lane, g, cur, fromX, Y, nullptr, d_sigma, mw, sr);
 }
 
+// `marked` null: one workgroup per tile.  Otherwise (the second launch behind the two-piece kernel) one word per tile, only
+// tiles whose word is not zero are computed, and a small grid walks the words.
+template <bool VIEWDIRS>
+__global__ void __launch_bounds__(X3_THREADS, 1)
+k_mlp_bwd_data_bf16x3(int64_t n_pts, int output_ch, const float* __restrict__ d_out, const float* __restrict__ act,
+                      const char* __restrict__ packed_x3, const char* __restrict__ packed_bwd, float* __restrict__ scr,
+                      const uint32_t* __restrict__ marked) {
+    const int64_t n_tiles = padded_points(n_pts) / TILE_PTS;
+    // workgroup b looks at the tiles b, b + G, b + 2 G, ... (G workgroups), X3_THREADS of them at a time, one word per
+    // thread, and works through the marked ones: neighbouring tiles go to different workgroups.  (Without `marked` the
+    // grid is the number of tiles and thread 0's tile, b, is the only one in range.)
+    __shared__ unsigned long long found[X3_WAVES];
+    const int tid = threadIdx.x;
+    for (int64_t base = blockIdx.x; base < n_tiles; base += (int64_t)gridDim.x * X3_THREADS) {
+        const int64_t mine = base + (int64_t)tid * gridDim.x;
+        const unsigned long long b = __ballot(mine < n_tiles && (marked == nullptr || marked[mine] != 0u));
+        if ((tid & 63) == 0) found[tid >> 6] = b;
+        __syncthreads();
+        for (int w = 0; w < X3_WAVES; ++w) {
+            unsigned long long todo = found[w];
+            while (todo != 0ull) {
+                const int i = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int64_t t = base + (int64_t)(64 * w + i) * gridDim.x;
+                bwd_tile_x3<VIEWDIRS>(t, n_pts, output_ch, d_out, act, packed_x3, packed_bwd, scr);
+                __syncthreads();      // (the next tile of this workgroup refills the LDS tables)
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // flat parameters -> transposed stream of triples
 __global__ void __launch_bounds__(256) k_pack_x3b(int use_viewdirs, int output_ch, const float* __restrict__ params,
                                                   char* __restrict__ out) {
@@ -291,7 +322,8 @@ int launch_bwd_data_x3(int64_t n_pts, int use_viewdirs, int output_ch, const flo
     auto go = [&](auto kernel, int och) -> int {
         hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), X3B_LDS_BYTES);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_bwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), X3B_LDS_BYTES, stream, n_pts, och, d_out, act,
+        const int64_t grid = (marked != nullptr && blocks > compute_units()) ? compute_units() : blocks;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(X3_THREADS), X3B_LDS_BYTES, stream, n_pts, och, d_out, act,
                            reinterpret_cast<const char*>(packed_x3), reinterpret_cast<const char*>(packed_bwd_x3), scratch, marked);
         return launched("nerf_mlp_bwd_bf16x3 (data)");
     };

@@ -132,14 +132,11 @@ __device__ __forceinline__ void layer_x3(Stream3& st, int lane, int g, const cha
     static_for<NPIECE>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
 }
 
+// one 128-point tile (tile_index) by one workgroup
 template <bool VIEWDIRS, bool SAVE>
-__global__ void __launch_bounds__(X3_THREADS, 1)
-k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
-                 int output_ch, const char* __restrict__ packed, float* __restrict__ out, float* __restrict__ act,
-                 const uint32_t* __restrict__ marked) {
-    // `marked` (may be null): one word per 128-point tile; only tiles whose word is not zero are computed (the tiles the
-    // two-piece fp16 kernel handed back, mlp_fwd_f16x2.hip)
-    if (marked != nullptr && marked[blockIdx.x] == 0u) return;
+__device__ __forceinline__ void fwd_tile_x3(int64_t tile_index, int64_t n_pts, int pts_per_ray, const float* __restrict__ pts,
+                                            const float* __restrict__ viewdirs, int output_ch, const char* __restrict__ packed,
+                                            float* __restrict__ out, float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     char* ring = smem3;
     float* aux = reinterpret_cast<float*>(smem3 + RING3_BYTES);
@@ -167,10 +164,10 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
     const int c0 = enc16_first_pair(g);
     // training: this workgroup's 128-point tile of the saved activations (mlp_layout.hpp)
     static_assert(X3_WG_PTS == TILE_PTS, "one workgroup per tile of the saved activations");
-    float* const tile = SAVE ? act + (int64_t)blockIdx.x * act_rows(UV) * TILE_PTS : nullptr;
+    float* const tile = SAVE ? act + tile_index * act_rows(UV) * TILE_PTS : nullptr;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        p[ct] = (int64_t)blockIdx.x * X3_WG_PTS + wave * WAVE_PTS + ct * 16 + (lane & 15);
+        p[ct] = tile_index * X3_WG_PTS + wave * WAVE_PTS + ct * 16 + (lane & 15);
         valid[ct] = p[ct] < n_pts;
         const int64_t pl = valid[ct] ? p[ct] : n_pts - 1;
         const float x0 = pts[pl * 3 + 0], x1 = pts[pl * 3 + 1], x2 = pts[pl * 3 + 2];
@@ -342,6 +339,39 @@ k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, 
 #undef X3_LAYER
 }
 
+// `marked` null: one workgroup per tile (the grid is the number of tiles).  Otherwise one word per 128-point tile, only
+// tiles whose word is not zero are computed (those the two-piece fp16 kernel handed back, mlp_fwd_f16x2.hip), and a small
+// grid walks the words: with nothing marked the launch is over in a few microseconds whatever the number of tiles.
+template <bool VIEWDIRS, bool SAVE>
+__global__ void __launch_bounds__(X3_THREADS, 1)
+k_mlp_fwd_bf16x3(int64_t n_pts, int pts_per_ray, const float* __restrict__ pts, const float* __restrict__ viewdirs,
+                 int output_ch, const char* __restrict__ packed, float* __restrict__ out, float* __restrict__ act,
+                 const uint32_t* __restrict__ marked) {
+    const int64_t n_tiles = (n_pts + X3_WG_PTS - 1) / X3_WG_PTS;
+    // workgroup b looks at the tiles b, b + G, b + 2 G, ... (G workgroups), X3_THREADS of them at a time, one word per
+    // thread, and works through the marked ones: neighbouring tiles go to different workgroups.  (Without `marked` the
+    // grid is the number of tiles and thread 0's tile, b, is the only one in range.)
+    __shared__ unsigned long long found[X3_WAVES];
+    const int tid = threadIdx.x;
+    for (int64_t base = blockIdx.x; base < n_tiles; base += (int64_t)gridDim.x * X3_THREADS) {
+        const int64_t mine = base + (int64_t)tid * gridDim.x;
+        const unsigned long long b = __ballot(mine < n_tiles && (marked == nullptr || marked[mine] != 0u));
+        if ((tid & 63) == 0) found[tid >> 6] = b;
+        __syncthreads();
+        for (int w = 0; w < X3_WAVES; ++w) {
+            unsigned long long todo = found[w];
+            while (todo != 0ull) {
+                const int i = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int64_t t = base + (int64_t)(64 * w + i) * gridDim.x;
+                fwd_tile_x3<VIEWDIRS, SAVE>(t, n_pts, pts_per_ray, pts, viewdirs, output_ch, packed, out, act);
+                __syncthreads();      // (the next tile of this workgroup refills the LDS tables)
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // flat parameters -> stream of triples + fp32 aux tables
 __global__ void __launch_bounds__(256) k_pack_bf16x3(int use_viewdirs, int output_ch, const float* __restrict__ params,
                                                      char* __restrict__ out) {
@@ -459,7 +489,8 @@ int nerf_mlp_fwd_bf16x3_marked(int64_t n_pts, int pts_per_ray, const float* pts,
         const size_t lds = x3_lds_bytes(use_viewdirs);
         hipError_t e = lds_limit_once(reinterpret_cast<const void*>(kernel), lds);
         if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16x3: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(X3_THREADS), lds, as_stream(stream), n_pts, ppr, pts,
+        const int64_t grid = (tile_flags != nullptr && blocks > compute_units()) ? compute_units() : blocks;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(X3_THREADS), lds, as_stream(stream), n_pts, ppr, pts,
                            vd, och, reinterpret_cast<const char*>(packed), out, act, tile_flags);
         return launched("nerf_mlp_fwd_bf16x3");
     };
