@@ -12,7 +12,8 @@ of one buffer per run, and so are the step counters, which the optimiser creates
 is not contiguous -- takes torch.optim.Adam.step() unchanged, on the same state.
 
 The step only enqueues work (learning rate and step count are read on the device when they live there), so it can be
-recorded into a HIP graph like the stock capturable optimiser.
+recorded into a HIP graph like the stock capturable optimiser -- after one eager step: the first step on a layout moves the
+moments into their buffers and reads one word back from the device.
 """
 from __future__ import annotations
 
