@@ -126,6 +126,16 @@ __device__ __forceinline__ void layer_x2(Stream2& st, int lane, int g, const cha
             }
             if constexpr (BIAS_INIT && to + 1 < NOUT && ks == NKS - 3) load_bias.template operator()<to + 1>();
         }
+        // Order inside a block: its two fragment reads, then every matrix instruction followed by two of the epilogue's
+        // vector instructions.  Left alone the scheduler issues the matrix instructions in runs of four and the vector
+        // instructions in runs of eight, during which the matrix pipe drains (1 % of a render's launch).
+        if constexpr (I >= DEPTH) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            static_for<3 * NCT2>([&]<int J>() {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            });
+        }
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<NPIECE>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
