@@ -120,15 +120,6 @@ __device__ __forceinline__ void layer_x2b(Stream2& st, int lane, int g, const ch
             }
             if constexpr (to + 1 < NOUT && ks == (NKS >= 4 ? NKS - 3 : 0)) load_start.template operator()<to + 1>();
         }
-#ifdef X2B_SGB
-        if constexpr (I >= DEPTH) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            static_for<3 * NCT2>([&]<int J>() {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, X2B_SGB, 0);
-            });
-        }
-#endif
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<NPIECE>([&]<int K>() { piece.template operator()<NOUT - 1, K>(); });
