@@ -337,6 +337,14 @@ int nerf_adam_step(int n_runs, const int64_t* counts, float* const* params, cons
                    float* const* exp_avg_sq, const float* const* step_dev, float step, const float* lr_dev, double lr,
                    double beta1, double beta2, double eps, double weight_decay, void* stream);
 
+/* The photometric loss of a batch and its gradient (upstream: img2mse = mean((x - y)^2), run_nerf_helpers.py:8, called
+ * on the fine and the coarse colours at run_nerf.py:863-869; the gradient is autograd's of that expression).  x, y: n
+ * DEVICE floats, 1 <= n <= nerf_mse_max_elems() (a training batch; one workgroup reduces it in fp64, in a fixed order);
+ * out: one DEVICE float.  nerf_mse_bwd: dx[i] = grad_out[0] * (2 / n) * (x[i] - y[i]), grad_out one DEVICE float. */
+int64_t nerf_mse_max_elems(void);
+int nerf_mse_fwd(int64_t n, const float* x, const float* y, float* out, void* stream);
+int nerf_mse_bwd(int64_t n, const float* x, const float* y, const float* grad_out, float* dx, void* stream);
+
 /* ---- nn.Linear for network shapes the fused kernels do not cover --------------------------------------------------
  * (other --netdepth / --netwidth / --multires, --i_embed -1: NeRF.forward layer by layer, run_nerf_helpers.py:109-133,
  * and autograd of it), fp32 on the fp32 matrix instruction; all pointers DEVICE, row-major, ld* = row strides in floats.

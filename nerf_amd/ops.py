@@ -741,6 +741,47 @@ def fused_mlp(pts: torch.Tensor, viewdirs: Optional[torch.Tensor], model, pts_pe
 
 
 # ------------------------------------------------------------------------------------------------
+# the photometric loss
+# ------------------------------------------------------------------------------------------------
+class _MSE(torch.autograd.Function):
+    """mean((x - y) ** 2) of two fp32 device tensors of one shape; the gradient flows to x only."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.nerf_mse_fwd(x.numel(), x.data_ptr(), y.data_ptr(), out.data_ptr(), _stream()))
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib.nerf_mse_bwd(x.numel(), x.data_ptr(), y.data_ptr(), g.data_ptr(), dx.data_ptr(), _stream()))
+        return dx, None
+
+
+_MSE_MAX = None
+
+
+def mse(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """img2mse (run_nerf_helpers.py:8): mean((x - y) ** 2).  A training batch on the device (fp32, one shape, contiguous,
+    no gradient wanted for y, at most nerf_mse_max_elems() elements) takes one launch forward and one backward; anything
+    else the stock fused mse_loss, which computes the same expression."""
+    global _MSE_MAX
+    if _MSE_MAX is None:
+        _MSE_MAX = int(lib.nerf_mse_max_elems())
+    if (torch.is_tensor(x) and torch.is_tensor(y) and x.is_cuda and y.is_cuda and x.device == y.device
+            and x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape and 0 < x.numel() <= _MSE_MAX
+            and x.is_contiguous() and y.is_contiguous() and not y.requires_grad):
+        return _MSE.apply(x, y)
+    return torch.nn.functional.mse_loss(x, y)
+
+
+# ------------------------------------------------------------------------------------------------
 # nn.Linear for shapes the fused kernels do not cover
 # ------------------------------------------------------------------------------------------------
 def _rows(t: torch.Tensor, what: str) -> torch.Tensor:

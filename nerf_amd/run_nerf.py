@@ -290,7 +290,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     N_rays = ray_batch.shape[0]
     dev = ray_batch.device
     rays_d = ray_batch[:, 3:6]
-    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
+    # (a column slice of the batch: made contiguous once here, not once per network inside the MLP call)
+    viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
 
     t_vals = ops.cached_linspace(N_samples, dev)
     t_rand = None
@@ -571,7 +572,7 @@ def train(argv=None):
     print('TRAIN views are', i_train)
     print('TEST views are', i_test)
     print('VAL views are', i_val)
-    loss = psnr = None
+    loss = None
     for i in range(start + 1, args.N_iters):
         batch_rays, target_s = batcher.next() if not args.no_batching else batcher.next(i)
 
@@ -580,7 +581,6 @@ def train(argv=None):
         optimizer.zero_grad()
         img_loss = img2mse(rgb, target_s)  # noqa: F405
         loss = img_loss
-        psnr = mse2psnr(img_loss)  # noqa: F405
         if 'rgb0' in extras:
             loss = loss + img2mse(extras['rgb0'], target_s)  # noqa: F405
         loss.backward()
@@ -617,6 +617,7 @@ def train(argv=None):
             if rank == 0:
                 print('Saved test set')
         if rank == 0 and i % args.i_print == 0:
+            psnr = mse2psnr(img_loss.detach())  # noqa: F405  (three launches: only when it is printed)
             print(f"[TRAIN] Iter: {i} Loss: {loss.item()}  PSNR: {psnr.item()}")
         global_step += 1
     return None if loss is None else float(loss.detach())

@@ -9,8 +9,9 @@ import torch.nn as nn
 from . import ops
 
 # Misc (run_nerf_helpers.py:8-10) -- the train-step tail stays in PyTorch.
-# (img2mse: mean((x - y) ** 2) as the library's fused mse_loss -- two launches forward and backward instead of eight)
-img2mse = lambda x, y: torch.nn.functional.mse_loss(x, y)
+# (img2mse: mean((x - y) ** 2); a training batch on the device takes one launch forward and one backward -- ops.mse --,
+# anything else torch's fused mse_loss)
+img2mse = lambda x, y: ops.mse(x, y)
 _LOG10 = {}
 
 

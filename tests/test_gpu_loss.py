@@ -1,0 +1,58 @@
+"""img2mse (upstream: run_nerf_helpers.py:8, called at run_nerf.py:863-869) through the library's one-launch loss and
+its one-launch gradient, against fp64 and against the stock expression."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_rays", [1, 7, 1024, 8192, 43690])
+def test_img2mse_matches_fp64_and_autograd(device, n_rays):
+    """Loss within one fp32 rounding of the fp64 mean of the fp32 squares (tolerance 1.2e-7 relative); the gradient
+    equals upstream * 2 / n * (x - y) to two roundings (2.4e-7 relative); both repeat bit for bit."""
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import img2mse
+    g = torch.Generator(device=device)
+    g.manual_seed(n_rays)
+    x = torch.rand(n_rays, 3, device=device, generator=g).requires_grad_(True)
+    y = torch.rand(n_rays, 3, device=device, generator=g)
+    loss = img2mse(x, y)
+    assert loss.grad_fn is not None and type(loss.grad_fn).__name__ == "_MSEBackward", "the library's loss did not run"
+    d = (x.detach() - y)
+    want = float((d * d).double().mean())
+    assert abs(float(loss) - want) <= 1.2e-7 * want + 1e-45
+    (loss * 3.0).backward()
+    want_g = (3.0 * 2.0 / x.numel()) * d.double()
+    err = float((x.grad.double() - want_g).abs().max())
+    assert err <= 2.4e-7 * float(want_g.abs().max()) + 1e-45
+    # the stock expression, for reference
+    x2 = x.detach().clone().requires_grad_(True)
+    (torch.mean((x2 - y) ** 2) * 3.0).backward()
+    assert float((x2.grad - x.grad).abs().max()) <= 2.4e-7 * float(want_g.abs().max())
+    again = img2mse(x, y)
+    assert torch.equal(again.detach(), loss.detach())
+    x.grad = None
+    (again * 3.0).backward()
+    assert torch.equal(x.grad, x2.grad * 0 + x.grad) and float((x.grad.double() - want_g).abs().max()) == err
+    assert ops.mse(x.detach(), y).shape == ()
+
+
+def test_img2mse_falls_back_where_the_kernel_does_not_apply(device):
+    """Broadcast shapes, strided views, a target that wants a gradient, more elements than one workgroup takes, CPU
+    tensors: the stock expression, same value."""
+    from nerf_amd._lib import lib
+    from nerf_amd.run_nerf_helpers import img2mse
+    torch.manual_seed(0)
+    big = int(lib.nerf_mse_max_elems()) // 3 + 1
+    x = torch.rand(big, 3, device=device, requires_grad=True)
+    y = torch.rand(big, 3, device=device)
+    cases = [(x, y), (x[:100, :2], y[:100, :2]), (x[:64], y[:64].clone().requires_grad_(True)), (x[:5].cpu(), y[:5].cpu())]
+    for a, b in cases:
+        got = img2mse(a, b)
+        assert type(got.grad_fn).__name__ != "_MSEBackward"
+        want = float(((a.detach().double() - b.detach().double()) ** 2).mean())
+        assert abs(float(got) - want) <= 1e-6 * want
+    with pytest.raises(RuntimeError):
+        from nerf_amd._lib import check
+        check(lib.nerf_mse_fwd(0, x.data_ptr(), y.data_ptr(), x.data_ptr(), None))
