@@ -49,6 +49,7 @@ class FlatAdam(torch.optim.Adam):
         self._layout_key = None
         self._static = False
         self.fast_steps = 0                                # steps taken through the library kernel (for tests and logs)
+        self._steps_all = {}                               # device -> [buffer of every run's step counters, words handed out]
 
     # ---- layout ------------------------------------------------------------------------------------
     @staticmethod
@@ -79,7 +80,7 @@ class FlatAdam(torch.optim.Adam):
         dev = run.params[0].device
         m = torch.zeros(run.numel, dtype=torch.float32, device=dev)
         v = torch.zeros(run.numel, dtype=torch.float32, device=dev)
-        steps = torch.zeros(len(run.params), dtype=torch.float32, device=dev)
+        steps = self._step_buffer(run, dev)
         off = 0
         for i, p in enumerate(run.params):
             st = self.state[p]
@@ -95,6 +96,33 @@ class FlatAdam(torch.optim.Adam):
         run.exp_avg, run.exp_avg_sq, run.steps = m, v, steps
         run.key = tuple(id(self.state[p]["exp_avg"]) for p in run.params)
         run.uniform = bool(steps.min() == steps.max())     # (a host read: adoption happens once, outside any recording)
+
+    def _step_buffer(self, run: _Run, dev) -> torch.Tensor:
+        """The step counters of a run: a slice of ONE buffer for every run on this device, so that a step increments
+        them all with one launch."""
+        n_all = sum(len(r.params) for runs in self._runs for r in runs)
+        buf = self._steps_all.get(dev)
+        if buf is None or buf[0].numel() != n_all:
+            buf = self._steps_all[dev] = [torch.zeros(n_all, dtype=torch.float32, device=dev), 0]
+        first = buf[1]
+        if first + len(run.params) > n_all:      # a layout adopted anew: start over (the values are copied in by the caller)
+            buf = self._steps_all[dev] = [torch.zeros(n_all, dtype=torch.float32, device=dev), 0]
+            first = 0
+        buf[1] = first + len(run.params)
+        return buf[0][first:first + len(run.params)]
+
+    @staticmethod
+    def _increment(runs) -> None:
+        """steps += 1 for every run: one launch per stretch of runs whose counters are adjacent slices of one buffer."""
+        i = 0
+        while i < len(runs):
+            j, n = i, runs[i].steps.numel()
+            while (j + 1 < len(runs) and runs[j + 1].steps.data_ptr() == runs[i].steps.data_ptr() + 4 * n
+                   and runs[j + 1].steps.untyped_storage().data_ptr() == runs[i].steps.untyped_storage().data_ptr()):
+                j += 1
+                n += runs[j].steps.numel()
+            (runs[i].steps if j == i else runs[i].steps.as_strided((n,), (1,))).add_(1.0)
+            i = j + 1
 
     def _state_intact(self, run: _Run) -> bool:
         if run.key is None:
@@ -137,8 +165,7 @@ class FlatAdam(torch.optim.Adam):
             super().step()              # parameters of one run at different step counts: the stock step keeps them apart
             return loss
         for group, runs in todo:
-            for run in runs:
-                run.steps.add_(1.0)
+            self._increment(runs)
             beta1, beta2 = group["betas"]
             lr = group["lr"]
             lr_dev = lr.data_ptr() if torch.is_tensor(lr) and lr.is_cuda else None

@@ -21,7 +21,7 @@ def test_img2mse_matches_fp64_and_autograd(device, n_rays):
     assert loss.grad_fn is not None and type(loss.grad_fn).__name__ == "_MSEBackward", "the library's loss did not run"
     d = (x.detach() - y)
     want = float((d * d).double().mean())
-    assert abs(float(loss) - want) <= 1.2e-7 * want + 1e-45
+    assert abs(float(loss.detach()) - want) <= 1.2e-7 * want + 1e-45
     (loss * 3.0).backward()
     want_g = (3.0 * 2.0 / x.numel()) * d.double()
     err = float((x.grad.double() - want_g).abs().max())
