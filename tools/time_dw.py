@@ -38,13 +38,17 @@ def call():
 for _ in range(3):
     call()
 torch.cuda.synchronize()
+from nerf_amd import gpustat  # noqa: E402
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-ev[0].record()
-for _ in range(reps):
-    call()
-ev[1].record()
-torch.cuda.synchronize()
+with gpustat.sampler_for(0, 0.02) as stat:
+    ev[0].record()
+    for _ in range(reps):
+        call()
+    ev[1].record()
+    torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / reps
+st = stat.summary()
 nbytes = n_pts * 4 * (2528 + 2432 + 12)
 print(f"{which} {os.environ.get('NERF_HIP_LIB', 'product'):40s} n_pts {n_pts}: {ms:.3f} ms  {n_pts * 1186816 / ms / 1e9:.1f} TFLOP/s alg  "
-      f"{nbytes / ms / 1e9:.2f} TB/s  checksum {float(d_params.double().abs().sum()):.6e}")
+      f"{nbytes / ms / 1e9:.2f} TB/s  checksum {float(d_params.double().abs().sum()):.6e}  "
+      f"{st['clock_ghz_mean']} GHz {st['power_w_mean']} W ({st['samples']} samples)")
