@@ -212,7 +212,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
     taken before the first collective of the leg; hook: called once after the warm-up steps (failure injection)."""
     from nerf_amd import gpustat, ops, parallel
     from nerf_amd.run_nerf import render
-    from nerf_amd.run_nerf_helpers import img2mse
+    from nerf_amd.run_nerf_helpers import img2mse_pair
     params = list(models[0].parameters()) + list(models[1].parameters())
     setup_error = None
     try:
@@ -267,7 +267,7 @@ def time_train(models, kwargs, dev, world, n_rand, steps, warmup, seed, graphed=
             return stepper.step(batch_rays, target)
         rgb, disp, acc, extras = render(H, W, K, chunk=1024 * 32, rays=batch_rays, verbose=False, retraw=True, **kw)
         opt.zero_grad()
-        loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
+        loss = img2mse_pair(rgb, extras['rgb0'], target)[2]     # both losses and their sum, as train() takes them
         loss.backward()
         if world > 1:   # the gradient exchange, bracketed by events on the stream the collectives are ordered on
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -344,6 +344,14 @@ int nerf_adam_step(int n_runs, const int64_t* counts, float* const* params, cons
 int64_t nerf_mse_max_elems(void);
 int nerf_mse_fwd(int64_t n, const float* x, const float* y, float* out, void* stream);
 int nerf_mse_bwd(int64_t n, const float* x, const float* y, const float* grad_out, float* dx, void* stream);
+/* Both losses of a step against one target in one launch (run_nerf.py:863-870: img_loss = img2mse(rgb, target_s),
+ * img_loss0 = img2mse(extras['rgb0'], target_s), loss = img_loss + img_loss0): out0, out1, out_sum one DEVICE float each,
+ * out_sum = out0 + out1 added in fp32.  nerf_mse_pair_bwd: d_k[i] = (grad_k[0] + grad_sum[0]) * (2 / n) * (x_k[i] - y[i]);
+ * each of grad0, grad1, grad_sum is one DEVICE float or NULL (no gradient arrived for that output). */
+int nerf_mse_pair_fwd(int64_t n, const float* x0, const float* x1, const float* y, float* out0, float* out1, float* out_sum,
+                      void* stream);
+int nerf_mse_pair_bwd(int64_t n, const float* x0, const float* x1, const float* y, const float* grad0, const float* grad1,
+                      const float* grad_sum, float* d0, float* d1, void* stream);
 
 /* ---- nn.Linear for network shapes the fused kernels do not cover --------------------------------------------------
  * (other --netdepth / --netwidth / --multires, --i_embed -1: NeRF.forward layer by layer, run_nerf_helpers.py:109-133,

@@ -69,6 +69,8 @@ SIGNATURES = {
     "nerf_mse_max_elems": (_l, []),
     "nerf_mse_fwd": (_i, [_l, _p, _p, _p, _p]),
     "nerf_mse_bwd": (_i, [_l, _p, _p, _p, _p, _p]),
+    "nerf_mse_pair_fwd": (_i, [_l, _p, _p, _p, _p, _p, _p, _p]),
+    "nerf_mse_pair_bwd": (_i, [_l, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_adam_max_runs": (_i, []),
     "nerf_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _d, _d, _d, _d, _d, _p]),
     "nerf_gather_split2": (_i, [_p, _p, _p, _l, _l, _l, _p]),

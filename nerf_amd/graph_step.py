@@ -22,7 +22,7 @@ from typing import Callable, Optional, Sequence
 
 import torch
 
-from .run_nerf_helpers import NeRF, img2mse
+from .run_nerf_helpers import NeRF, img2mse, img2mse_pair
 
 
 class GraphedTrainStep:
@@ -63,10 +63,10 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         rgb, disp, acc, extras = self.render_fn(self.H, self.W, self.K, chunk=self.chunk, rays=self.rays, verbose=False,
                                                 retraw=True, **self.kwargs)
-        img_loss = img2mse(rgb, self.target)
-        loss = img_loss
         if 'rgb0' in extras:
-            loss = loss + img2mse(extras['rgb0'], self.target)
+            img_loss, _, loss = img2mse_pair(rgb, extras['rgb0'], self.target)
+        else:
+            loss = img_loss = img2mse(rgb, self.target)
         loss.backward()
         self.loss.copy_(loss.detach())
         # mse2psnr with the constant folded on the host (a host-built tensor cannot be uploaded while recording)

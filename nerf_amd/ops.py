@@ -764,6 +764,32 @@ class _MSE(torch.autograd.Function):
         return dx, None
 
 
+class _MSEPair(torch.autograd.Function):
+    """(mean((x0 - y) ** 2), mean((x1 - y) ** 2), their sum) in one launch; the gradients of both inputs in one more."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, y):
+        out = [torch.empty((), dtype=torch.float32, device=x0.device) for _ in range(3)]
+        with torch.cuda.device(x0.device):
+            check(lib.nerf_mse_pair_fwd(x0.numel(), x0.data_ptr(), x1.data_ptr(), y.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                        out[2].data_ptr(), _stream()))
+        ctx.save_for_backward(x0, x1, y)
+        ctx.set_materialize_grads(False)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g_sum):
+        x0, x1, y = ctx.saved_tensors
+        if g0 is None and g1 is None and g_sum is None:
+            return None, None, None
+        gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g0, g1, g_sum)]
+        d0, d1 = torch.empty_like(x0), torch.empty_like(x1)
+        with torch.cuda.device(x0.device):
+            check(lib.nerf_mse_pair_bwd(x0.numel(), x0.data_ptr(), x1.data_ptr(), y.data_ptr(), _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]),
+                                        d0.data_ptr(), d1.data_ptr(), _stream()))
+        return d0, d1, None
+
+
 _MSE_MAX = None
 
 
@@ -779,6 +805,21 @@ def mse(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
             and x.is_contiguous() and y.is_contiguous() and not y.requires_grad):
         return _MSE.apply(x, y)
     return torch.nn.functional.mse_loss(x, y)
+
+
+def mse_pair(x0: torch.Tensor, x1: torch.Tensor, y: torch.Tensor):
+    """Both losses of a training step against one target (run_nerf.py:863-870) -> (mse(x0, y), mse(x1, y), their sum):
+    one launch forward and one backward where `mse` would take one each per term, plus the addition."""
+    global _MSE_MAX
+    if _MSE_MAX is None:
+        _MSE_MAX = int(lib.nerf_mse_max_elems())
+    ts = (x0, x1, y)
+    if (all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+            and x0.device == y.device and x1.device == y.device and x0.shape == y.shape and x1.shape == y.shape
+            and 0 < y.numel() <= _MSE_MAX and not y.requires_grad):
+        return _MSEPair.apply(x0, x1, y)
+    a, b = mse(x0, y), mse(x1, y)
+    return a, b, a + b
 
 
 # ------------------------------------------------------------------------------------------------

@@ -579,10 +579,10 @@ def train(argv=None):
         rgb, disp, acc, extras = render(H, W, K, chunk=args.chunk, rays=batch_rays, verbose=i < 10, retraw=True,
                                         **render_kwargs_train)
         optimizer.zero_grad()
-        img_loss = img2mse(rgb, target_s)  # noqa: F405
-        loss = img_loss
         if 'rgb0' in extras:
-            loss = loss + img2mse(extras['rgb0'], target_s)  # noqa: F405
+            img_loss, _, loss = img2mse_pair(rgb, extras['rgb0'], target_s)  # noqa: F405
+        else:
+            loss = img_loss = img2mse(rgb, target_s)  # noqa: F405
         loss.backward()
         if world > 1:
             parallel.allreduce_gradients(grad_vars)

@@ -12,6 +12,9 @@ from . import ops
 # (img2mse: mean((x - y) ** 2); a training batch on the device takes one launch forward and one backward -- ops.mse --,
 # anything else torch's fused mse_loss)
 img2mse = lambda x, y: ops.mse(x, y)
+# (the two losses of a step, img2mse(rgb, target) and img2mse(rgb0, target), and their sum from one launch:
+#  -> (img_loss, img_loss0, loss); upstream computes them at run_nerf.py:863-870)
+img2mse_pair = lambda x, x0, y: ops.mse_pair(x, x0, y)
 _LOG10 = {}
 
 

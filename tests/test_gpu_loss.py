@@ -52,7 +52,45 @@ def test_img2mse_falls_back_where_the_kernel_does_not_apply(device):
         got = img2mse(a, b)
         assert type(got.grad_fn).__name__ != "_MSEBackward"
         want = float(((a.detach().double() - b.detach().double()) ** 2).mean())
-        assert abs(float(got) - want) <= 1e-6 * want
+        assert abs(float(got.detach()) - want) <= 1e-6 * want
     with pytest.raises(RuntimeError):
         from nerf_amd._lib import check
         check(lib.nerf_mse_fwd(0, x.data_ptr(), y.data_ptr(), x.data_ptr(), None))
+
+
+@pytest.mark.parametrize("n_rays", [1, 1024, 8192])
+def test_img2mse_pair_equals_the_two_losses_and_their_sum(device, n_rays):
+    """One launch for both losses of a step: the same bits as img2mse on each input, their fp32 sum, and the gradients
+    autograd gives the expression img2mse(x, t) + img2mse(x0, t) -- also when a gradient arrives for one loss alone or
+    for all three outputs, and when none arrives for one of the inputs."""
+    from nerf_amd.run_nerf_helpers import img2mse, img2mse_pair
+    g = torch.Generator(device=device)
+    g.manual_seed(7 + n_rays)
+    x = torch.rand(n_rays, 3, device=device, generator=g).requires_grad_(True)
+    x0 = torch.rand(n_rays, 3, device=device, generator=g).requires_grad_(True)
+    t = torch.rand(n_rays, 3, device=device, generator=g)
+    a, b, total = img2mse_pair(x, x0, t)
+    assert type(total.grad_fn).__name__ == "_MSEPairBackward", "the library's paired loss did not run"
+    ra, rb = img2mse(x.detach().requires_grad_(True), t), img2mse(x0.detach().requires_grad_(True), t)
+    assert torch.equal(a.detach(), ra.detach()) and torch.equal(b.detach(), rb.detach())
+    assert torch.equal(total.detach(), (ra + rb).detach())
+    total.backward()
+    xr, x0r = x.detach().clone().requires_grad_(True), x0.detach().clone().requires_grad_(True)
+    (img2mse(xr, t) + img2mse(x0r, t)).backward()
+    assert torch.equal(x.grad, xr.grad) and torch.equal(x0.grad, x0r.grad)
+    # gradients for single outputs and for a mix
+    x.grad = x0.grad = None
+    a, b, total = img2mse_pair(x, x0, t)
+    (2.0 * a).backward()
+    assert float(x0.grad.abs().max()) == 0.0
+    assert float((x.grad - 2.0 * xr.grad).abs().max()) <= 2.4e-7 * float(xr.grad.abs().max()) * 2.0
+    x.grad = x0.grad = None
+    a, b, total = img2mse_pair(x, x0, t)
+    (a + 3.0 * b + total).backward()
+    assert float((x.grad - 2.0 * xr.grad).abs().max()) <= 5e-7 * float(xr.grad.abs().max())
+    assert float((x0.grad - 4.0 * x0r.grad).abs().max()) <= 1e-6 * float(x0r.grad.abs().max())
+    # where the kernel does not apply: the same three values from the single losses
+    a2, b2, t2 = img2mse_pair(x[:, ::2], x0[:, ::2], t[:, ::2])      # (every other column: not contiguous, even for one row)
+    assert type(t2.grad_fn).__name__ != "_MSEPairBackward"
+    want = float(((x.detach()[:, ::2].double() - t[:, ::2].double()) ** 2).mean() + ((x0.detach()[:, ::2].double() - t[:, ::2].double()) ** 2).mean())
+    assert abs(float(t2.detach()) - want) <= 1e-6 * want

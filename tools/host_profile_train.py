@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import bench  # noqa: E402
 from nerf_amd.raybatch import ViewSampler  # noqa: E402
 from nerf_amd.run_nerf import render  # noqa: E402
-from nerf_amd.run_nerf_helpers import img2mse  # noqa: E402
+from nerf_amd.run_nerf_helpers import img2mse_pair  # noqa: E402
 
 n_rand = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -36,7 +36,7 @@ def one(i):
     rays, target = sampler.next(i, img_i=i % 4)
     rgb, disp, acc, extras = render(H, W, K, chunk=1024 * 32, rays=rays, verbose=False, retraw=True, **kw)
     opt.zero_grad()
-    loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
+    loss = img2mse_pair(rgb, extras['rgb0'], target)[2]
     loss.backward()
     opt.step()
     return loss

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 from nerf_amd.optim import FlatAdam  # noqa: E402
 from nerf_amd.raybatch import ViewSampler  # noqa: E402
 from nerf_amd.run_nerf import render  # noqa: E402
-from nerf_amd.run_nerf_helpers import img2mse  # noqa: E402
+from nerf_amd.run_nerf_helpers import img2mse_pair  # noqa: E402
 
 n_rand = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev = torch.device("cuda", 0)
@@ -32,7 +32,7 @@ def one(i):
     rays, target = sampler.next(i, img_i=i % 4)
     rgb, disp, acc, extras = render(H, W, K, chunk=1024 * 32, rays=rays, verbose=False, retraw=True, **kw)
     opt.zero_grad()
-    loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
+    loss = img2mse_pair(rgb, extras['rgb0'], target)[2]
     loss.backward()
     opt.step()
     return loss

@@ -25,7 +25,7 @@ from nerf_amd.datasets import pose_spherical  # noqa: E402
 from nerf_amd.optim import FlatAdam  # noqa: E402
 from nerf_amd.raybatch import ViewSampler  # noqa: E402
 from nerf_amd.run_nerf import render, run_network  # noqa: E402
-from nerf_amd.run_nerf_helpers import NeRF, get_embedder, img2mse, mse2psnr  # noqa: E402
+from nerf_amd.run_nerf_helpers import NeRF, get_embedder, img2mse, img2mse_pair, mse2psnr  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 out_path = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/soak/soak_train.json"
@@ -79,7 +79,7 @@ for kind in ("f16x2", "bf16x3", "f32_mfma"):
         rgb, _, _, ex = render(H, W, K, chunk=1 << 15, rays=rays, retraw=True, network_fn=student[0], network_fine=student[1],
                                perturb=1.0, raw_noise_std=0.0, **common)
         opt.zero_grad()
-        loss = img2mse(rgb, target) + img2mse(ex["rgb0"], target)
+        loss = img2mse_pair(rgb, ex["rgb0"], target)[2]
         loss.backward()
         opt.step()
         for g in opt.param_groups:
