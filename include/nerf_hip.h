@@ -269,6 +269,10 @@ int nerf_mlp_bwd_bf16x3(int64_t n_pts, const float* d_out, const float* act, int
 int64_t nerf_mlp_bf16x3_triples(int use_viewdirs);
 int nerf_gather_split3(const int32_t* table, const float* params, void* out, int64_t triples0, int64_t n_aux,
                        int64_t triples1, void* stream);
+/* nerf_gather_split2 (out2) and nerf_gather_split3 (out3) of one network in ONE launch: all four weight streams a training
+ * step on the default kernels reads.  Arguments as in the two calls. */
+int nerf_gather_split23(const int32_t* table2, const int32_t* table3, const float* params, void* out2, void* out3, int64_t pairs,
+                        int64_t n_aux2, int64_t pairs1, int64_t triples0, int64_t n_aux3, int64_t triples1, void* stream);
 
 /* The two stages of nerf_mlp_bwd_bf16x3 as separate calls (same arguments; the stages communicate through `scratch`
  * only, so a caller can time them, or overlap other work between them): _data fills the dY rows of every layer

@@ -402,31 +402,7 @@ __global__ void __launch_bounds__(256) k_pack_bf16x3(int use_viewdirs, int outpu
 // its two sources, splits them and writes one 4-byte word per piece.  seg0 triples | aux floats | seg1 triples.
 __global__ void __launch_bounds__(256) k_gather_split3(const int32_t* __restrict__ table, const float* __restrict__ params,
                                                        char* __restrict__ out, int64_t triples0, int64_t n_aux, int64_t triples1) {
-    const int64_t pairs0 = triples0 * 256, pairs1 = triples1 * 256;
-    const int64_t total = pairs0 + n_aux + pairs1;
-    char* seg1 = out + triples0 * TRIPLE_BYTES + n_aux * 4;
-    const int32_t* tab1 = table + triples0 * 512 + n_aux;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i >= pairs0 && i < pairs0 + n_aux) {
-            const int64_t a = i - pairs0;
-            const int32_t s = table[triples0 * 512 + a];
-            reinterpret_cast<float*>(out + triples0 * TRIPLE_BYTES)[a] = s < 0 ? 0.0f : params[s];
-            continue;
-        }
-        const bool second = i >= pairs0;
-        const int64_t q = second ? i - pairs0 - n_aux : i;
-        const int2 s = reinterpret_cast<const int2*>(second ? tab1 : table)[q];
-        __bf16 h0, m0, l0, h1, m1, l1;
-        split3(s.x < 0 ? 0.0f : params[s.x], h0, m0, l0);
-        split3(s.y < 0 ? 0.0f : params[s.y], h1, m1, l1);
-        auto word = [](__bf16 a, __bf16 b) {
-            return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-        };
-        unsigned* dst = reinterpret_cast<unsigned*>((second ? seg1 : out) + (q >> 8) * TRIPLE_BYTES) + (q & 255);
-        dst[0] = word(h0, h1);
-        dst[256] = word(m0, m1);
-        dst[512] = word(l0, l1);
-    }
+    gather_split3_elements(table, params, out, triples0, n_aux, triples1);
 }
 
 constexpr size_t x3_lds_bytes(int uv) { return RING3_BYTES + aux_floats(uv) * sizeof(float) + X3_WAVES * 3 * enc_frags(uv) * 64 * 16; }

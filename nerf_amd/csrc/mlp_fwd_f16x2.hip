@@ -18,6 +18,7 @@
 #include "mlp_tile16.hpp"
 #include "mlp_bf16_layout.hpp"
 #include "mlp_x2.hpp"
+#include "mlp_x3.hpp"
 
 using namespace nerfhip;
 using namespace nerflayout;
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(256) k_pack_f16x2(int use_viewdirs, int output
 // sources, splits them and writes one 4-byte word per piece; then the fp32 tables; the range words as in k_pack_f16x2;
 // behind them a second stream of pair blocks (the transposed one of mlp_bwd_f16x2.hip), whose elements are the same
 // weights again and do not count for the range words.
-__global__ void __launch_bounds__(256) k_gather_split2(const int32_t* __restrict__ table, const float* __restrict__ params,
+__device__ __forceinline__ void gather_split2_elements(const int32_t* __restrict__ table, const float* __restrict__ params,
                                                        char* __restrict__ out, int64_t npairs, int64_t n_aux, int64_t npairs1) {
     const int64_t words = npairs * 256;            // two stream elements each
     const int64_t first = words + n_aux, total = first + npairs1 * 256;
@@ -494,6 +495,21 @@ __global__ void __launch_bounds__(256) k_gather_split2(const int32_t* __restrict
         br.add(mag, i < words ? x2_block_section((int)(i >> 8)) : 0);   // a wave's 64 words lie in one block, hence in one section
     }
     br.end(range);
+}
+
+__global__ void __launch_bounds__(256) k_gather_split2(const int32_t* __restrict__ table, const float* __restrict__ params,
+                                                       char* __restrict__ out, int64_t npairs, int64_t n_aux, int64_t npairs1) {
+    gather_split2_elements(table, params, out, npairs, n_aux, npairs1);
+}
+
+// nerf_gather_split2 and nerf_gather_split3 of one network in one launch: every stream a training step on the default
+// kernels reads (both fp16-pair streams, both bf16-triple streams) from one pass of the grid over both maps
+__global__ void __launch_bounds__(256) k_gather_split23(const int32_t* __restrict__ table2, const int32_t* __restrict__ table3,
+                                                        const float* __restrict__ params, char* __restrict__ out2,
+                                                        char* __restrict__ out3, int64_t npairs, int64_t n_aux2, int64_t npairs1,
+                                                        int64_t triples0, int64_t n_aux3, int64_t triples1) {
+    gather_split2_elements(table2, params, out2, npairs, n_aux2, npairs1);
+    nerfx3::gather_split3_elements(table3, params, out3, triples0, n_aux3, triples1);
 }
 
 constexpr size_t x2_lds_bytes(int uv) {
@@ -539,6 +555,24 @@ int nerf_gather_split2(const int32_t* table, const float* params, void* out, int
     hipLaunchKernelGGL(k_gather_split2, dim3(256), dim3(256), 0, as_stream(stream), table, params, reinterpret_cast<char*>(out),
                        pairs, n_aux, pairs1);
     return launched("nerf_gather_split2");
+}
+
+int nerf_gather_split23(const int32_t* table2, const int32_t* table3, const float* params, void* out2, void* out3, int64_t pairs,
+                        int64_t n_aux2, int64_t pairs1, int64_t triples0, int64_t n_aux3, int64_t triples1, void* stream) {
+    NERF_REQUIRE(pairs > 0 && n_aux2 >= 0 && pairs1 >= 0 && triples0 > 0 && n_aux3 >= 0 && triples1 >= 0, "nerf_gather_split23: counts");
+    NERF_REQUIRE(table2 && table3 && params && out2 && out3, "nerf_gather_split23: null pointer");
+    NERF_REQUIRE(pairs % SLABP == 0 && pairs1 % SLABP == 0 && n_aux2 % 4 == 0 && n_aux3 % 4 == 0,
+                 "nerf_gather_split23: pairs=%lld and pairs1=%lld must be whole slabs, n_aux2=%lld and n_aux3=%lld multiples of 4",
+                 (long long)pairs, (long long)pairs1, (long long)n_aux2, (long long)n_aux3);
+    NERF_REQUIRE(((reinterpret_cast<uintptr_t>(table2) | reinterpret_cast<uintptr_t>(table3)) & 7) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(out2) | reinterpret_cast<uintptr_t>(out3)) & 15) == 0,
+                 "nerf_gather_split23: tables must be 8-byte and outputs 16-byte aligned");
+    char* range = reinterpret_cast<char*>(out2) + pairs * PAIR_BYTES + n_aux2 * 4;
+    hipError_t e = hipMemsetAsync(range, 0, RANGE_WORDS * 4, as_stream(stream));
+    if (e != hipSuccess) return fail(NERF_E_LAUNCH, "nerf_gather_split23: clearing the range words: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gather_split23, dim3(1024), dim3(256), 0, as_stream(stream), table2, table3, params,
+                       reinterpret_cast<char*>(out2), reinterpret_cast<char*>(out3), pairs, n_aux2, pairs1, triples0, n_aux3, triples1);
+    return launched("nerf_gather_split23");
 }
 
 int nerf_mlp_fwd_f16x2(int64_t n_pts, int pts_per_ray, const float* pts, const float* viewdirs, int use_viewdirs,

@@ -593,6 +593,22 @@ def x3_pack_table(use_viewdirs: bool, output_ch: int, dev):
     return (src.to(torch.int32) - 1).contiguous(), t0, n_aux, t1
 
 
+def pack_weights_train_streams(flat: torch.Tensor, x2_table, x3_table):
+    """(fp16-pair stream, its transposed stream, bf16-triple stream, its transposed stream) of one network from ONE
+    gather-and-split launch; x2_table / x3_table as x2_pack_table / x3_pack_table return them."""
+    flat = _f32c(flat, "params")
+    table2, pairs, n_aux2, pairs1 = x2_table
+    table3, t0, n_aux3, t1 = x3_table
+    n2 = pairs * 2048 + n_aux2 * 4 + 64
+    n3 = t0 * 3072 + n_aux3 * 4
+    out2 = torch.empty(n2 + pairs1 * 2048, dtype=torch.uint8, device=flat.device)
+    out3 = torch.empty(n3 + t1 * 3072, dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_gather_split23(table2.data_ptr(), table3.data_ptr(), flat.data_ptr(), out2.data_ptr(), out3.data_ptr(),
+                                      pairs, n_aux2, pairs1, t0, n_aux3, t1, _stream()))
+    return out2[:n2], out2[n2:], out3[:n3], out3[n3:]
+
+
 def pack_weights_x3_pair(flat: torch.Tensor, table: torch.Tensor, t0: int, n_aux: int, t1: int):
     """-> (forward split stream with its fp32 tables, transposed split stream): one gather-and-split launch."""
     flat = _f32c(flat, "params")

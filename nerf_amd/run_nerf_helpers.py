@@ -287,10 +287,20 @@ class NeRF(nn.Module):
         """Everything a training step on the default kernels reads, with ONE look at the parameters: (flat parameters,
         fp16-pair stream, its transposed stream, bf16-triple stream, its transposed stream)."""
         flat = self._flat()
-        if self._pack16x2 is None or self._pack16x2b is None:
-            self._packed_f16x2(with_bwd=True)
-        if self._pack16x3 is None or self._pack16x3b is None:
-            self._packed_x3_pair()
+        need2 = self._pack16x2 is None or self._pack16x2b is None
+        need3 = self._pack16x3 is None or self._pack16x3b is None
+        if need2 and need3:      # (the case of every training step: all four streams from one launch)
+            if self._x2_table is None or self._x2_table[0].device != flat.device:
+                self._x2_table = ops.x2_pack_table(self.use_viewdirs, self.output_ch, flat.device)
+            if self._x3_table is None or self._x3_table[0].device != flat.device:
+                self._x3_table = ops.x3_pack_table(self.use_viewdirs, self.output_ch, flat.device)
+            self._pack16x2, self._pack16x2b, self._pack16x3, self._pack16x3b = ops.pack_weights_train_streams(
+                flat, self._x2_table, self._x3_table)
+        else:
+            if need2:
+                self._packed_f16x2(with_bwd=True)
+            if need3:
+                self._packed_x3_pair()
         return flat, self._pack16x2, self._pack16x2b, self._pack16x3, self._pack16x3b
 
     def _packed_bwd_bf16x3(self):

@@ -144,3 +144,8 @@ def test_pair_stream_from_one_gather_equals_the_packing_kernel(device, use_viewd
         assert torch.equal(at, ops.pack_weights_bwd_f16x2(flat, use_viewdirs, output_ch)), scale
         a0, none = ops.pack_weights_f16x2_gather(flat, *table[:3])
         assert none is None and torch.equal(a0, b), scale
+        # all four streams of a training step from ONE launch: the bits of the two separate gathers
+        table3 = ops.x3_pack_table(use_viewdirs, output_ch, device)
+        f2, b2, f3, b3 = ops.pack_weights_train_streams(flat, table, table3)
+        g3, g3t = ops.pack_weights_x3_pair(flat, *table3)
+        assert torch.equal(f2, a) and torch.equal(b2, at) and torch.equal(f3, g3) and torch.equal(b3, g3t), scale
