@@ -335,17 +335,11 @@ int nerf_mlp_bwd_weights_f16x2(int64_t n_pts, const float* act, int use_viewdirs
  * every assignment rounded to fp32, as the library optimiser's fused kernel computes them.  t, the count of this update
  * (1 for the first): step_dev[i] points to run i's count as a DEVICE float (the caller increments it beforehand; a graph
  * replay then reads the current value), or step_dev = NULL (or an entry NULL) and `step` is used.  lr_dev: the learning
- * rate as a DEVICE float, or NULL and `lr` is used.  amsgrad / maximize are not covered.
- * A counting launch (step_counts and ticket not NULL; step_dev required): step_dev[i] points to the step_counts[i] counters
- * of run i (HOST array of ints; one counter per parameter tensor, all equal) as they stand BEFORE this update; the kernel
- * works with that count + 1 and writes the new count into every counter itself (the workgroup that finishes last does),
- * so the caller launches no increment.  ticket: one DEVICE word that is 0 before the first such launch; the kernel leaves
- * it at 0.  Launches that share a ticket must not overlap. */
+ * rate as a DEVICE float, or NULL and `lr` is used.  amsgrad / maximize are not covered. */
 int nerf_adam_max_runs(void);
 int nerf_adam_step(int n_runs, const int64_t* counts, float* const* params, const float* const* grads, float* const* exp_avg,
-                   float* const* exp_avg_sq, float* const* step_dev, float step, const float* lr_dev, double lr,
-                   double beta1, double beta2, double eps, double weight_decay, const int* step_counts, uint32_t* ticket,
-                   void* stream);
+                   float* const* exp_avg_sq, const float* const* step_dev, float step, const float* lr_dev, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 /* The photometric loss of a batch and its gradient (upstream: img2mse = mean((x - y)^2), run_nerf_helpers.py:8, called
  * on the fine and the coarse colours at run_nerf.py:863-869; the gradient is autograd's of that expression).  x, y: n

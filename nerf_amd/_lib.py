@@ -72,7 +72,7 @@ SIGNATURES = {
     "nerf_mse_pair_fwd": (_i, [_l, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_mse_pair_bwd": (_i, [_l, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nerf_adam_max_runs": (_i, []),
-    "nerf_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _d, _d, _d, _d, _d, _p, _p, _p]),
+    "nerf_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _d, _d, _d, _d, _d, _p]),
     "nerf_gather_split2": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "nerf_gather_split23": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _p]),
     "nerf_mlp_packed_bwd_f16x2_bytes": (_l, [_i]),

@@ -19,9 +19,7 @@ struct AdamRuns {
     float* v[ADAM_MAX_RUNS];
     int64_t first[ADAM_MAX_RUNS + 1];   // first 4-element chunk of every run among all chunks of the launch
     int64_t count[ADAM_MAX_RUNS];       // elements
-    float* step[ADAM_MAX_RUNS];         // the run's step counters on the device (the first one is read); or null: AdamConst::step
-    int step_n[ADAM_MAX_RUNS];          // counting launches: how many counters the run has (one per parameter tensor)
-    uint32_t* ticket;                   // counting launches: a device word that is 0 between launches; else null
+    const float* step[ADAM_MAX_RUNS];   // the step count of this update (already incremented), on the device; or null: AdamConst::step
     int aligned[ADAM_MAX_RUNS];         // all four pointers 16-byte aligned
     int n;
 };
@@ -41,24 +39,17 @@ __device__ __forceinline__ void adam_one(float& p, float g32, float& m, float& v
     p = (float)(p - (float)step_size * m / denom);
 }
 
-// A counting launch (r.ticket) reads the counters as they stood BEFORE this update, works with that count + 1, and the
-// workgroup that finishes last writes the new count into every counter: one launch instead of an increment and a launch.
-// (Every workgroup reads the count at its start and takes its ticket at its end, so the last one writes after all reads.)
 __global__ void __launch_bounds__(ADAM_THREADS) k_adam(AdamRuns r, AdamConst c) {
     __shared__ double sh_step_size[ADAM_MAX_RUNS], sh_bc2_sqrt[ADAM_MAX_RUNS];
-    __shared__ float sh_step[ADAM_MAX_RUNS];
-    __shared__ int sh_last;
     if ((int)threadIdx.x < r.n) {   // per run: its bias corrections from its own step count
-        double step = r.step[threadIdx.x] ? (double)*r.step[threadIdx.x] : (double)c.step;
-        if (r.ticket && r.step[threadIdx.x]) step += 1.0;
-        sh_step[threadIdx.x] = (float)step;
+        const double step = r.step[threadIdx.x] ? (double)*r.step[threadIdx.x] : (double)c.step;
         const double lr = c.lr_dev ? (double)*c.lr_dev : c.lr;
         sh_step_size[threadIdx.x] = lr / (1.0 - pow(c.beta1, step));
         sh_bc2_sqrt[threadIdx.x] = sqrt(1.0 - pow(c.beta2, step));
     }
     __syncthreads();
     const int64_t chunk = (int64_t)blockIdx.x * ADAM_THREADS + threadIdx.x;
-    if (chunk < r.first[r.n]) {
+    if (chunk >= r.first[r.n]) return;
     int i = 0;
 #pragma unroll
     for (int k = 1; k < ADAM_MAX_RUNS; ++k)
@@ -85,21 +76,6 @@ __global__ void __launch_bounds__(ADAM_THREADS) k_adam(AdamRuns r, AdamConst c) 
     } else {
         for (int e = 0; e < 4 && e < left; ++e) adam_one(p[e], g[e], m[e], v[e], c, step_size, bc2_sqrt);
     }
-    }
-    if (r.ticket) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            sh_last = atomicAdd(r.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
-        }
-        __syncthreads();
-        if (sh_last) {
-            for (int i = 0; i < r.n; ++i)
-                if (r.step[i])
-                    for (int k = threadIdx.x; k < r.step_n[i]; k += ADAM_THREADS) r.step[i][k] = sh_step[i];
-            if (threadIdx.x == 0) atomicExch(r.ticket, 0u);
-        }
-    }
 }
 
 }  // namespace
@@ -109,13 +85,11 @@ extern "C" {
 int nerf_adam_max_runs(void) { return ADAM_MAX_RUNS; }
 
 int nerf_adam_step(int n_runs, const int64_t* counts, float* const* params, const float* const* grads, float* const* exp_avg,
-                   float* const* exp_avg_sq, float* const* step_dev, float step, const float* lr_dev, double lr, double beta1,
-                   double beta2, double eps, double weight_decay, const int* step_counts, uint32_t* ticket, void* stream) {
+                   float* const* exp_avg_sq, const float* const* step_dev, float step, const float* lr_dev, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, void* stream) {
     NERF_REQUIRE(n_runs >= 0 && n_runs <= ADAM_MAX_RUNS, "nerf_adam_step: n_runs=%d not in 0..%d", n_runs, ADAM_MAX_RUNS);
     if (n_runs == 0) return 0;
     NERF_REQUIRE(counts && params && grads && exp_avg && exp_avg_sq, "nerf_adam_step: null pointer");
-    NERF_REQUIRE((step_counts == nullptr) == (ticket == nullptr), "nerf_adam_step: step_counts and ticket go together");
-    NERF_REQUIRE(!ticket || step_dev, "nerf_adam_step: a counting launch needs the device step counters");
     NERF_REQUIRE(step_dev || step >= 1.0f, "nerf_adam_step: step=%g (the count of this update, starting at 1)", (double)step);
     AdamRuns r{};
     int64_t chunks = 0;
@@ -125,8 +99,6 @@ int nerf_adam_step(int n_runs, const int64_t* counts, float* const* params, cons
         r.p[i] = params[i]; r.g[i] = grads[i]; r.m[i] = exp_avg[i]; r.v[i] = exp_avg_sq[i];
         r.count[i] = counts[i];
         r.step[i] = step_dev ? step_dev[i] : nullptr;
-        r.step_n[i] = step_counts ? step_counts[i] : 0;
-        NERF_REQUIRE(!ticket || (r.step[i] && r.step_n[i] >= 1), "nerf_adam_step: run %d of a counting launch has no step counters", i);
         NERF_REQUIRE(r.step[i] || step >= 1.0f, "nerf_adam_step: run %d has no device step counter and step=%g", i, (double)step);
         r.aligned[i] = ((reinterpret_cast<uintptr_t>(params[i]) | reinterpret_cast<uintptr_t>(grads[i]) |
                          reinterpret_cast<uintptr_t>(exp_avg[i]) | reinterpret_cast<uintptr_t>(exp_avg_sq[i])) & 15) == 0;
@@ -135,7 +107,6 @@ int nerf_adam_step(int n_runs, const int64_t* counts, float* const* params, cons
     }
     for (int i = n_runs; i <= ADAM_MAX_RUNS; ++i) r.first[i] = chunks;
     r.n = n_runs;
-    r.ticket = ticket;
     if (chunks == 0) return 0;
     const int64_t blocks = (chunks + ADAM_THREADS - 1) / ADAM_THREADS;
     NERF_REQUIRE(blocks <= 0x7fffffff, "nerf_adam_step: too many elements for one launch");

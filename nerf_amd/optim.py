@@ -4,8 +4,8 @@
 constructor arguments, `param_groups`, `state` and `state_dict()` / `load_state_dict()` format.  When every parameter of
 a step lies in a run of parameters whose storage is contiguous (a NeRF module keeps its parameters as views of one flat
 vector) and whose gradients are laid out the same way (the fused MLP's backward returns views of one flat gradient, and
-the data-parallel exchange reduces it in place), the whole update is ONE launch of the library's Adam kernel, which also
-counts the step, instead of the stock implementation's multi-tensor launches of 64 Ki elements per block
+the data-parallel exchange reduces it in place), the whole update is ONE launch of the library's Adam kernel plus one
+increment of the step counters, instead of the stock implementation's multi-tensor launches of 64 Ki elements per block
 (three under-filled launches, 100 us, for the 1.2 M parameters of a coarse + fine pair).  The moments of a run are views
 of one buffer per run, and so are the step counters, which the optimiser creates on first use -- or rebuilds from whatever
 `load_state_dict` put in their place.  Anything else -- a parameter without a gradient, amsgrad, maximize, a layout that
@@ -49,7 +49,6 @@ class FlatAdam(torch.optim.Adam):
         self._layout_key = None
         self._static = False
         self.fast_steps = 0                                # steps taken through the library kernel (for tests and logs)
-        self._tickets = {}
         self._steps_all = {}                               # device -> [buffer of every run's step counters, words handed out]
 
     # ---- layout ------------------------------------------------------------------------------------
@@ -112,12 +111,18 @@ class FlatAdam(torch.optim.Adam):
         buf[1] = first + len(run.params)
         return buf[0][first:first + len(run.params)]
 
-    def _ticket(self, dev) -> torch.Tensor:
-        """The device word the counting launches of this optimiser share on `dev` (0 between launches)."""
-        t = self._tickets.get(dev)
-        if t is None:
-            t = self._tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-        return t
+    @staticmethod
+    def _increment(runs) -> None:
+        """steps += 1 for every run: one launch per stretch of runs whose counters are adjacent slices of one buffer."""
+        i = 0
+        while i < len(runs):
+            j, n = i, runs[i].steps.numel()
+            while (j + 1 < len(runs) and runs[j + 1].steps.data_ptr() == runs[i].steps.data_ptr() + 4 * n
+                   and runs[j + 1].steps.untyped_storage().data_ptr() == runs[i].steps.untyped_storage().data_ptr()):
+                j += 1
+                n += runs[j].steps.numel()
+            (runs[i].steps if j == i else runs[i].steps.as_strided((n,), (1,))).add_(1.0)
+            i = j + 1
 
     def _state_intact(self, run: _Run) -> bool:
         if run.key is None:
@@ -160,6 +165,7 @@ class FlatAdam(torch.optim.Adam):
             super().step()              # parameters of one run at different step counts: the stock step keeps them apart
             return loss
         for group, runs in todo:
+            self._increment(runs)
             beta1, beta2 = group["betas"]
             lr = group["lr"]
             lr_dev = lr.data_ptr() if torch.is_tensor(lr) and lr.is_cuda else None
@@ -173,14 +179,12 @@ class FlatAdam(torch.optim.Adam):
                     part = runs[a:a + max_runs]
                     n = len(part)
                     counts = (ctypes.c_int64 * n)(*[r.numel for r in part])
-                    step_counts = (ctypes.c_int * n)(*[len(r.params) for r in part])
                     arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)      # noqa: E731
                     check(lib.nerf_adam_step(n, counts, arr([r.params[0].data_ptr() for r in part]),
                                              arr([r.params[0].grad.data_ptr() for r in part]),
                                              arr([r.exp_avg.data_ptr() for r in part]), arr([r.exp_avg_sq.data_ptr() for r in part]),
                                              arr([r.steps.data_ptr() for r in part]), 0.0, lr_dev, lr_val, float(beta1), float(beta2),
-                                             float(group["eps"]), float(group["weight_decay"]), step_counts,
-                                             self._ticket(dev).data_ptr(), stream))
+                                             float(group["eps"]), float(group["weight_decay"]), stream))
         self.fast_steps += 1
         return loss
 
