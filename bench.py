@@ -842,15 +842,18 @@ def main():
     if not args.no_train:
         ready = legs.ready if world > 1 else None
         # configs[0]/[3]: lego train step at N_rand = 1024 (the upstream config) and 8192 rays per GPU (data parallel)
-        for key, n_rand, k, w, seed in (("train_8192", 8192, 10, 2, 4321), ("train", 1024, 20, 5, 1234)):
+        # (warm-up: after the host-side set-up between two legs the shader clock needs tens of milliseconds of work to come
+        #  back -- a kernel behind a 5 ms pause runs 16 % slower, tools/probe_idle_credit.py --, which is a whole 1024-ray leg
+        #  of a few steps: these legs warm up for 0.15-0.2 s and time 30-40 steps)
+        for key, n_rand, k, w, seed in (("train_8192", 8192, 10, 4, 4321), ("train", 1024, 40, 40, 1234)):
             extra(key, lambda key=key, n_rand=n_rand, k=k, w=w, seed=seed: again_if_launch_bound(lambda: time_train(
                 models, kwargs, dev, world, n_rand, k, w, seed=seed + rank, ready=ready, card=card,
                 hook=lambda key=key: injected_failure(key))), collective=True)
         if world == 1:   # configs[2]: fern-shaped step (NDC, density noise, 64 + 64 samples), single-GPU extra
             extra("train_fern", lambda: again_if_launch_bound(
-                lambda: time_train(models, kwargs, dev, world, 1024, 10, 3, seed=99, scene="fern", card=card)))
+                lambda: time_train(models, kwargs, dev, world, 1024, 30, 40, seed=99, scene="fern", card=card)))
         if world == 1:   # single-GPU extra; the multi-rank runs keep to the eager step
-            extra("train_graphed", lambda: time_train(models, kwargs, dev, world, 1024, 10, 5, seed=1234 + rank, graphed=True, card=card))
+            extra("train_graphed", lambda: time_train(models, kwargs, dev, world, 1024, 30, 40, seed=1234 + rank, graphed=True, card=card))
 
     if rank == 0:
         guard.arm("cpu_baseline", 900.0)
