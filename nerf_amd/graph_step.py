@@ -1,6 +1,6 @@
 """The optimisation step (run_nerf.py:856-883) recorded into HIP graphs.
 
-At the upstream batch size (N_rand = 1024) a step is about 49 launches, of which six (the MLP kernels) carry 94 % of
+At the upstream batch size (N_rand = 1024) a step is about 41 launches, of which six (the MLP kernels) carry 94 % of
 the GPU time; the rest are microsecond kernels.  Eager, the launching thread needs about half the step's 4.6 ms for them,
 which is fine until the host's cores are contended and the thread falls behind the GPU.  The whole
 step -- render with gradients, the two MSE terms, backward, Adam -- only enqueues work on the current stream, so it can
