@@ -47,3 +47,18 @@ for idle_ms in (0, 5, 20, 100, 0):
     s = st.summary()
     print(f"idle {idle_ms:3d} ms before every launch: mean {sum(ms) / len(ms):.3f} ms, median {ms[len(ms) // 2]:.3f}, min {ms[0]:.3f}; "
           f"sampled {s['clock_ghz_mean']} GHz {s['power_w_mean']} W", flush=True)
+
+# how long the clock takes to come back: ten launches back to back behind one 100 ms pause, each timed
+for kernel_pts in (n_rays * S, n_rays * S // 16):
+    sub_pts, sub_vd = pts[:kernel_pts], vd[:kernel_pts // S]
+    torch.cuda.synchronize()
+    time.sleep(0.1)
+    evs = []
+    for _ in range(24):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.mlp_forward_f16x2(sub_pts, sub_vd, m._packed_f16x2(), None, True, 5, S)
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    print(f"behind a 100 ms pause, {kernel_pts} points per launch, ms per launch:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in evs), flush=True)
