@@ -149,3 +149,14 @@ def test_pair_stream_from_one_gather_equals_the_packing_kernel(device, use_viewd
         f2, b2, f3, b3 = ops.pack_weights_train_streams(flat, table, table3)
         g3, g3t = ops.pack_weights_x3_pair(flat, *table3)
         assert torch.equal(f2, a) and torch.equal(b2, at) and torch.equal(f3, g3) and torch.equal(b3, g3t), scale
+    # argument errors of the one-launch form: counts that are not whole slabs, a missing table
+    from nerf_amd._lib import NerfHipError, check, lib
+    t2, pairs, n_aux2, pairs1 = table
+    t3, t0, n_aux3, t1 = table3
+    out = torch.empty(64, dtype=torch.uint8, device=device)
+    with pytest.raises(NerfHipError, match="whole slabs"):
+        check(lib.nerf_gather_split23(t2.data_ptr(), t3.data_ptr(), flat.data_ptr(), out.data_ptr(), out.data_ptr(), pairs + 1, n_aux2,
+                                      pairs1, t0, n_aux3, t1, None))
+    with pytest.raises(NerfHipError, match="null pointer"):
+        check(lib.nerf_gather_split23(t2.data_ptr(), None, flat.data_ptr(), out.data_ptr(), out.data_ptr(), pairs, n_aux2, pairs1, t0,
+                                      n_aux3, t1, None))
