@@ -54,7 +54,9 @@ def run(cases: int, seed: int) -> int:
         gs = float(raw_ref.grad.abs().max())
         err = float((rg.grad.cpu().double() - raw_ref.grad).abs().max())
         err_cpu = float((raw32.grad.double() - raw_ref.grad).abs().max())   # the fp32 CPU evaluation against the same truth
-        report("composite grad", err <= max(1e-4 * gs, 2.0 * err_cpu, 1e-9), (n, S, scale, white, err, err_cpu, gs))
+        # (floor: a third of an fp32 rounding of the O(1) colours and upstream gradients -- with raw values of scale 100 every
+        #  sample saturates, the true gradients are 1e-8 and smaller, and weights below 1e-45 are zero in fp32)
+        report("composite grad", err <= max(1e-4 * gs, 2.0 * err_cpu, 2e-8), (n, S, scale, white, err, err_cpu, gs))
 
         # ---- coarse depths
         Sc = int(rng.choice([3, 4, 9, 64, 65, 128, 256]))

@@ -1,6 +1,6 @@
 """Random ragged batches through the fused MLP on every arithmetic of the training step, forward and parameter gradients,
 against an fp64 evaluation of the module's definition (run_nerf_helpers.py:109-133 and autograd of it) in plain torch
-on the same device: python3 tools/fuzz_mlp.py [cases] [seed]
+on the same device: python3 tools/fuzz_mlp.py [cases] [seed] [case,case,...]
 
 Per case: a network with random weights (gain 0.25 .. 4 over the hidden layers, with or without the view branch), a ragged
 batch (1 .. 3000 rays x 1 .. 130 samples, positions of scale 0.1 .. 30), an upstream gradient whose colour and density
@@ -52,7 +52,7 @@ def evaluate(m, pts, vd, n_rays, S, dtype):
     return F.linear(h, m.output_linear.weight, m.output_linear.bias), margin
 
 
-def run(cases: int, seed: int) -> int:
+def run(cases: int, seed: int, only=None) -> int:
     rng = np.random.Generator(np.random.PCG64(seed))
     dev = torch.device("cuda", torch.cuda.current_device())
     bad = 0
@@ -79,6 +79,8 @@ def run(cases: int, seed: int) -> int:
         d_out = torch.randn(n_rays * S, n_out, device=dev, generator=g)
         d_out[..., :3] *= float(rng.choice([1.0, 1e-3, 1e-6, 1e3]))
         d_out *= float(rng.choice([1.0, 1e-4, 1e2]))
+        if only is not None and case not in only:      # (the case's draws are made: the following cases stay what they were)
+            continue
         # fp64 truth, the per-point margin, and what plain fp32 torch makes of the same module (its error is the yardstick
         # for sums that cancel: a bias gradient is a column sum of the upstream gradient)
         m64, m32 = copy.deepcopy(m).double(), copy.deepcopy(m)
@@ -113,9 +115,15 @@ def run(cases: int, seed: int) -> int:
                 ts = float(t.abs().max())
                 err = float((q.grad.double() - t).abs().max()) / (ts + 1e-300) if ts > 0 else float(q.grad.abs().max())
                 worst[kind][1] = max(worst[kind][1], err)
-                if not err <= max(5e-5, 2.0 * err32.get(name, 0.0) / (ts + 1e-300)):
+                # (the gradient of a head's bias is a plain column sum of the upstream gradient: when it cancels to 1e-5 of
+                #  the sum of its terms' magnitudes, an error of 1e-9 of that sum is large in the units above; allow 1e-7 of it)
+                cancel = 1e-7 * float(d_out.double().abs().sum(0).max()) / (ts + 1e-300) if name.endswith("_linear.bias") else 0.0
+                if not err <= max(5e-5, 2.0 * err32.get(name, 0.0) / (ts + 1e-300), cancel):
                     bad += 1
                     print("MISMATCH grad", kind, name, case, what, err, flush=True)
+                    if only is not None and t.numel() <= 8:
+                        print("   truth", t.flatten().tolist(), "got", q.grad.flatten().tolist(), "plain fp32 torch error", err32.get(name),
+                              "sum |terms| of the last column", float(d_out[:, -1].double().abs().sum()), flush=True)
         ops.MARKED = None
         if (case + 1) % 20 == 0:
             print(f"{case + 1} cases, {bad} mismatches, marked tiles {marked[0]} of {marked[1]}, worst (out, grad) {worst}", flush=True)
@@ -125,4 +133,5 @@ def run(cases: int, seed: int) -> int:
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
-    sys.exit(min(run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0), 100))
+    only = set(int(c) for c in sys.argv[3].split(",")) if len(sys.argv) > 3 else None      # evaluate these cases only
+    sys.exit(min(run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0, only), 100))
